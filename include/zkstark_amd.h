@@ -1,0 +1,169 @@
+/*
+ * zkstark_amd.h -- C ABI of the MI355X-native STARK-101 prover path.
+ *
+ * Drop-in boundary for the hot path of Crocodoctopus/zkstark
+ * (trace -> LDE -> Merkle commit -> composition -> FRI fold -> proof).  The
+ * reference is a bin-only Rust crate with no FFI; the seams below are the L0
+ * functions prover.rs calls.  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the Rust `extern "C"` block and the prover.rs-shaped
+ * wrapper a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ZK_OK, negative = error (never aborts,
+ *     never throws across the boundary; the reference panics instead);
+ *     zk_last_error() gives the message of the last failure on this thread;
+ *   - the caller owns all host buffers; device state lives behind zk_ctx;
+ *   - one context is used from one host thread at a time;
+ *   - field elements cross as uint32_t canonical residues in [0, P),
+ *     P = 3221225473 (main.rs:13); raw u32 challenges >= P are accepted and
+ *     reduced inside (field.rs:20-24);
+ *   - digests cross as 32 raw bytes in SHA-256 byte order (merkle.rs:9 Hash);
+ *   - layers and trees are addressed by id: 0 = f_eval (prover.rs:70, :81),
+ *     1 + r = FRI layer r (cp_evals[r] / cp_eval_merkles[r], prover.rs:192-221),
+ *     r = 0 .. log_n.
+ */
+#ifndef ZKSTARK_AMD_H
+#define ZKSTARK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_FIELD_P 3221225473u
+
+enum zk_status {
+    ZK_OK = 0,
+    ZK_ERR_INVALID = -1,  /* bad argument (size not a power of two, out of range, ...) */
+    ZK_ERR_HIP = -2,      /* HIP runtime / kernel failure */
+    ZK_ERR_NOMEM = -3,
+    ZK_ERR_STATE = -4,    /* stage called out of order */
+    ZK_ERR_BUFFER = -5,   /* caller buffer too small */
+    ZK_ERR_VERIFY = -6,   /* proof rejected (reference: panic in Proof::verify) */
+    ZK_ERR_CHECK = -7     /* prover self-check failed (reference: assert_eq! in prover.rs) */
+};
+
+typedef struct zk_ctx zk_ctx;
+
+const char *zk_last_error(void);
+const char *zk_version(void);
+
+/* ---- scalar field helpers on the host: field.rs:8-211 ------------------- */
+uint32_t zk_field_add(uint32_t a, uint32_t b);       /* field.rs:99-111 */
+uint32_t zk_field_sub(uint32_t a, uint32_t b);       /* field.rs:113-132 */
+uint32_t zk_field_mul(uint32_t a, uint32_t b);       /* field.rs:134-167 */
+uint32_t zk_field_neg(uint32_t a);                   /* field.rs:198-203 */
+uint32_t zk_field_inv(uint32_t a);                   /* field.rs:205-210 */
+uint32_t zk_field_pow(uint32_t a, uint32_t e);       /* field.rs:26-38 */
+uint32_t zk_field_from_u32(uint32_t v);              /* field.rs:20-24 */
+uint32_t zk_field_generator(void);                   /* field.rs:52-86 -> 5 */
+uint32_t zk_field_root_of_unity(uint32_t log_order); /* prover.rs:48-49 */
+
+/* ---- context ------------------------------------------------------------- */
+/* Allocates HBM for a proof with trace group size n = 2^log_n and blow-up
+ * B = 2^log_blowup (reference literals: 10 and 3, prover.rs:48-57), builds the
+ * twiddle and denominator tables.  One-time cost; zk_ctx_setup_ms reports it. */
+int zk_ctx_create(int device, uint32_t log_n, uint32_t log_blowup, zk_ctx **out);
+int zk_ctx_destroy(zk_ctx *ctx);
+double zk_ctx_setup_ms(const zk_ctx *ctx);
+size_t zk_ctx_device_bytes(const zk_ctx *ctx);
+int zk_ctx_sync(zk_ctx *ctx);
+/* The HIP stream every stage is enqueued on (hipStream_t). */
+void *zk_ctx_stream(zk_ctx *ctx);
+
+/* ---- trace: prover.rs:32-42 ---------------------------------------------- */
+/* a0, a1, a[i] = a[i-2]^2 + a[i-1]^2 on the host (serial recurrence). */
+int zk_trace_fibsq(uint32_t a0, uint32_t a1, size_t count, uint32_t *out);
+/* Uploads the n-1 trace values (prover.rs:60 interpolates exactly n-1 points). */
+int zk_trace_upload(zk_ctx *ctx, const uint32_t *trace, size_t count);
+
+/* ---- stages on context-resident data --------------------------------------- */
+/* lagrange (polynomial.rs:337) + solve over w*h^i (polynomial.rs:49, prover.rs:60-70):
+ * layer 0 <- f(w h^i), i < N, natural order. */
+int zk_lde(zk_ctx *ctx);
+/* Merkle::new over a layer (merkle.rs:14-51; prover.rs:81, :176, :214); root = node 0. */
+int zk_merkle_commit(zk_ctx *ctx, uint32_t layer, uint8_t root_out[32]);
+/* Constraint quotients and their random combination (prover.rs:101-173):
+ * layer 1 <- cp(w h^i).  alpha_raw are the raw u32 challenges (prover.rs:163-165). */
+int zk_compose(zk_ctx *ctx, const uint32_t alpha_raw[3]);
+/* fri() + squared half domain + re-evaluation (polynomial.rs:385, prover.rs:198-211):
+ * layer 2+round <- fold(layer 1+round, beta). */
+int zk_fri_fold(zk_ctx *ctx, uint32_t round, uint32_t beta_raw);
+/* Small device->host reads (decommit, tests). */
+int zk_layer_read(zk_ctx *ctx, uint32_t layer, size_t offset, size_t count, uint32_t *out);
+int zk_layer_write(zk_ctx *ctx, uint32_t layer, size_t offset, size_t count, const uint32_t *in);
+/* Index<usize> for Merkle (merkle.rs:74-79). */
+int zk_merkle_node(zk_ctx *ctx, uint32_t tree, size_t index, uint8_t out[32]);
+/* Merkle::trace (merkle.rs:54-71): sibling of the leaf first, child of the root last.
+ * out holds 32 * log2(m) bytes; *path_len receives log2(m). */
+int zk_merkle_path(zk_ctx *ctx, uint32_t tree, size_t leaf, uint8_t *out, size_t *path_len);
+
+/* ---- whole prover: generate_proof (prover.rs:9-293) ------------------------- */
+/* Runs from "trace resident on device" (zk_trace_upload) to "proof bytes on host".
+ * proof_out receives Channel.data (channel.rs:8), state_out Channel.state
+ * (channel.rs:34-36), i.e. the two fields of Proof (proof.rs:5-8). */
+int zk_prove_resident(zk_ctx *ctx, uint8_t *proof_out, size_t cap, size_t *proof_len,
+                      uint8_t state_out[32]);
+/* zk_trace_upload + zk_prove_resident. */
+int zk_prove(zk_ctx *ctx, const uint32_t *trace, size_t count, uint8_t *proof_out, size_t cap,
+             size_t *proof_len, uint8_t state_out[32]);
+/* Challenges and checkpoints of the last zk_prove* on this context (tests/diagnostics). */
+typedef struct zk_transcript_info {
+    uint32_t alpha_raw[3];
+    uint32_t beta_raw[32];
+    uint32_t free_term;
+    uint32_t query_raw;
+    uint32_t public_last; /* a[n-2] */
+    uint8_t roots[34][32]; /* trees 0 .. log_n + 1 */
+} zk_transcript_info;
+int zk_last_transcript(const zk_ctx *ctx, zk_transcript_info *out);
+/* Per-stage device time of the last zk_prove* in milliseconds (HIP events on the ctx
+ * stream): [0] lde, [1] merkle, [2] compose, [3] fri fold, [4] decommit gather. */
+int zk_last_stage_ms(const zk_ctx *ctx, double out[5]);
+/* Per-stage event timing is off by default (it adds event records to the stream). */
+int zk_ctx_set_profiling(zk_ctx *ctx, int on);
+
+/* ---- proof: proof.rs ------------------------------------------------------- */
+/* Proof::verify (proof.rs:15-149), CPU only, generalised from the literals
+ * (1024, 8192, 10, 2338775057) to (log_n, log_blowup, public_last). */
+int zk_verify(const uint8_t *proof, size_t len, uint32_t log_n, uint32_t log_blowup,
+              uint32_t public_last);
+/* Proof::size (proof.rs:151-154). */
+size_t zk_proof_size(size_t data_len);
+size_t zk_proof_data_len(uint32_t log_n, uint32_t log_blowup);
+/* compute_root_from_path (merkle.rs:82-110), CPU. */
+int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t *path, size_t path_len,
+                              uint8_t out[32]);
+
+/* ---- Channel (channel.rs:6-37), host only ------------------------------------ */
+typedef struct zk_channel zk_channel;
+int zk_channel_new(zk_channel **out);                                        /* channel.rs:12 */
+int zk_channel_free(zk_channel *ch);
+int zk_channel_commit(zk_channel *ch, const uint8_t *bytes, size_t n);       /* channel.rs:19 */
+int zk_channel_get_u32(zk_channel *ch, uint32_t *out);                       /* channel.rs:28 */
+int zk_channel_state(const zk_channel *ch, uint8_t out[32]);
+size_t zk_channel_data_len(const zk_channel *ch);
+int zk_channel_data(const zk_channel *ch, uint8_t *out, size_t cap);         /* channel.rs:34 */
+
+/* ---- stand-alone primitives on host buffers (upload, run on the GPU, download) -- */
+/* Merkle::new(size, data) (merkle.rs:14): nodes_out = (2m-1)*32 bytes, heap order. */
+int zk_merkle_build_host(int device, const uint32_t *vals, size_t m, uint8_t *nodes_out);
+/* Natural-order NTT / inverse NTT of size 2^log_m with the canonical root
+ * zk_field_root_of_unity(log_m); in place on the host buffer. */
+int zk_ntt_host(int device, uint32_t *data, uint32_t log_m, int inverse);
+/* trace (n-1 values) -> N coset evaluations (same as zk_trace_upload + zk_lde + read). */
+int zk_lde_host(int device, const uint32_t *trace, uint32_t log_n, uint32_t log_blowup, uint32_t *out);
+
+/* ---- device-pointer primitives (stream-ordered; for external orchestration) ---- */
+/* d_vals: m u32 on the device; d_nodes: (2m-1)*8 u32 state words, heap order. */
+int zk_dev_merkle_build(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_nodes, void *stream);
+/* Byte view of nodes stored as state words: out[32] for node `index`. */
+int zk_dev_merkle_node(const uint32_t *d_nodes, size_t index, uint8_t out[32], void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (oracle/): the checker, never the thing under test on the GPU side."""
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def zk():
+    import zkstark_amd
+    zkstark_amd.load()
+    return zkstark_amd

@@ -1,0 +1,158 @@
+"""GPU parity: each HIP stage against the CPU oracle on the same seeded inputs (bit-exact).
+
+All calls go through the C ABI (ctypes -> libzkstark_amd.so).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 3221225473
+
+
+def rand_field(rng, n):
+    return rng.integers(0, P, size=n, dtype=np.uint64).astype(np.uint32)
+
+
+# ---- Merkle (merkle.rs) -----------------------------------------------------------
+def test_merkle_reference_vectors(zk):
+    """merkle_test, merkle.rs:112-182: leaves [1,2,3,4], all 7 nodes, 4 paths, root from path."""
+    m = zk.Merkle.new(4, [1, 2, 3, 4])
+    i3 = "b40711a88c7039756fb8a73827eabe2c0fe5a0346ca7e0a104adc0fc764f528d"
+    i4 = "433ebf5bc03dffa38536673207a21281612cef5faa9bc7a4d5b9be2fdb12cf1a"
+    i5 = "88185d128d9922e0e6bcd32b07b6c7f20f27968eab447a1d8d1cdf250f79f7d3"
+    i6 = "1bc5d0e3df0ea12c4d0078668d14924f95106bbe173e196de50fe13a900b0937"
+    i1 = "be8dc357decb6e09c8e5ad874d3c4fa7fc09730bbb5e90f42c97dad20e0012d4"
+    i2 = "6bed5b6d7ae093d1812ab9be5cbfa1ce787812a003d95c11448720a407b61727"
+    i0 = "327cf213e1738de4206bfd14297c26c682961750cb56897ed5e8f519b0548ff2"
+    assert [m[i].hex() for i in range(7)] == [i0, i1, i2, i3, i4, i5, i6]
+    assert [h.hex() for h in m.trace(0)] == [i4, i2]
+    assert [h.hex() for h in m.trace(1)] == [i3, i2]
+    assert [h.hex() for h in m.trace(2)] == [i6, i1]
+    assert [h.hex() for h in m.trace(3)] == [i5, i1]
+    assert zk.compute_root_from_path(1, 0, m.trace(0)) == m[0]
+
+
+@pytest.mark.parametrize("log_m", [0, 1, 2, 5, 10, 11, 12, 13, 16, 19, 20])
+def test_merkle_matches_oracle(zk, orc, log_m):
+    rng = np.random.default_rng(100 + log_m)
+    vals = rand_field(rng, 1 << log_m)
+    vals[0] = 0
+    if log_m:
+        vals[1] = P - 1
+    got = zk.Merkle.new(1 << log_m, vals).nodes
+    want = orc.merkle_build(vals)
+    assert got.shape == want.shape
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+def test_merkle_rejects_non_power_of_two(zk):
+    with pytest.raises(zk.ZkError):      # merkle.rs:18 assert_eq!(i % 2, 0)
+        zk.Merkle.new(6, [1, 2, 3, 4, 5, 6])
+    with pytest.raises(zk.ZkError):
+        zk.Merkle.new(0, [])
+
+
+# ---- NTT ------------------------------------------------------------------------
+@pytest.mark.parametrize("log_m", [1, 2, 3, 7, 8, 9, 10, 13, 14, 16, 17, 20])
+def test_ntt_forward_inverse_match_oracle(zk, orc, log_m):
+    rng = np.random.default_rng(200 + log_m)
+    x = rand_field(rng, 1 << log_m)
+    root = orc.gen_of_order_log(log_m)
+    fwd = zk.ntt(x)
+    assert np.array_equal(fwd, orc.ntt(x, root))
+    inv = zk.ntt(x, inverse=True)
+    assert np.array_equal(inv, orc.intt(x, root))
+    assert np.array_equal(zk.ntt(fwd, inverse=True), x)
+
+
+# ---- LDE (polynomial.rs lagrange + solve; prover.rs:60-78) -------------------------
+def test_lde_reference_checkpoints(zk):
+    """prover.rs:42, :73-78."""
+    a = zk.trace_fibsq(1023)
+    assert a[1022] == 2338775057
+    f = zk.lde(a, 10, 3)
+    assert list(f[:3]) == [576067152, 3100214617, 2091264768]
+    assert list(f[-3:]) == [800520420, 1199720174, 1076821037]
+
+
+@pytest.mark.parametrize("log_n,log_b", [(2, 1), (3, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1)])
+def test_lde_matches_oracle(zk, orc, log_n, log_b):
+    rng = np.random.default_rng(300 + log_n * 8 + log_b)
+    trace = rand_field(rng, (1 << log_n) - 1)   # arbitrary trace values, not only Fibonacci-square
+    got = zk.lde(trace, log_n, log_b)
+    assert np.array_equal(got, orc.lde(trace, log_n, log_b))
+
+
+# ---- composition + fold (prover.rs:101-225) --------------------------------------------
+@pytest.mark.parametrize("log_n,log_b", [(2, 1), (4, 3), (10, 3), (13, 2), (16, 3)])
+def test_compose_and_fold_match_oracle(zk, orc, log_n, log_b):
+    rng = np.random.default_rng(400 + log_n)
+    N = 1 << (log_n + log_b)
+    f = rand_field(rng, N)
+    alphas = [int(rng.integers(0, 2**32)) for _ in range(3)]
+    alphas[1] = 3235878091   # >= P: must be reduced (field.rs:20-24)
+    with zk.Context(log_n, log_b) as ctx:
+        trace = rand_field(rng, (1 << log_n) - 1)
+        trace[0] = 1   # a[0]: prover.rs:101 uses a[0], the verifier the literal 1 (proof.rs:69)
+        ctx.trace_upload(trace)
+        ctx.layer_write(0, f)
+        ctx.compose(alphas)
+        cp = ctx.layer_read(1)
+        assert np.array_equal(cp, orc.compose(f, log_n, log_b, alphas, int(trace[-1])))
+        layer = cp
+        for r in range(log_n):
+            beta = int(rng.integers(0, 2**32)) if r != 1 else 4195595581
+            ctx.fri_fold(r, beta)
+            nxt = ctx.layer_read(2 + r)
+            assert np.array_equal(nxt, orc.fri_fold_eval(layer, log_n, log_b, r, beta)), f"round {r}"
+            layer = nxt
+
+
+# ---- whole prover ---------------------------------------------------------------------
+def test_prover_canonical_run(zk, orc):
+    """generate_proof at the reference's literals: proof bytes equal to the oracle's, verifier accepts."""
+    want = orc.prove(10, 3)
+    with zk.Context(10, 3) as ctx:
+        proof = ctx.prove(zk.trace_fibsq(1023))
+        info = ctx.last_transcript()
+        assert list(info.alpha_raw) == want.alpha_raw
+        assert list(info.beta_raw)[:10] == want.beta_raw
+        for t in range(12):
+            assert bytes(info.roots[t]) == bytes(want.roots[t])
+        assert info.free_term == want.free_term and info.query_raw == want.query_raw
+    assert proof.data == want.proof and proof.state == want.state
+    assert hashlib.sha256(proof.data).hexdigest() == "b956f69349dfb74d2facd9f886efa8b983fb61f17bd95cab2e3449fc57b4bb2e"
+    proof.verify()
+    assert proof.size() == 7884
+    assert orc.verify(proof.data, 10, 3, 2338775057) == 0
+
+
+def test_generate_proof_staged_equals_one_call(zk):
+    """The prover.rs-shaped staged flow over the C ABI and the one-call C++ prover agree."""
+    p1 = zk.generate_proof(zk.Channel())
+    with zk.Context(10, 3) as ctx:
+        p2 = ctx.prove(zk.trace_fibsq(1023))
+    assert p1.data == p2.data and p1.state == p2.state
+    p1.verify()
+
+
+@pytest.mark.parametrize("log_n,log_b,a1", [(2, 1, 3141592), (3, 3, 7), (6, 2, 3141592), (12, 3, 99), (15, 3, 3141592), (17, 3, 5)])
+def test_prover_other_sizes(zk, orc, log_n, log_b, a1):
+    want = orc.prove(log_n, log_b, 1, a1, want_vectors=False)
+    assert want.rc == 0
+    with zk.Context(log_n, log_b) as ctx:
+        proof = ctx.prove(zk.trace_fibsq((1 << log_n) - 1, 1, a1))
+    assert proof.data == want.proof and proof.state == want.state
+    proof.verify()
+
+
+def test_prover_rejects_bad_trace(zk):
+    """A trace that breaks the recurrence must not yield a proof (reference: assert/panic)."""
+    a = zk.trace_fibsq(1023)
+    a[500] = (int(a[500]) + 1) % P
+    with zk.Context(10, 3) as ctx:
+        with pytest.raises(zk.ZkError):
+            ctx.prove(a)

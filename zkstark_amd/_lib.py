@@ -1,0 +1,110 @@
+"""ctypes loader for libzkstark_amd.so (the C ABI declared in include/zkstark_amd.h).
+
+There is no CPU fallback: if the library is missing and cannot be built with
+hipcc, importing raises.  Compute entry points need a visible MI355X.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkstark_amd.so")
+
+ZK_OK = 0
+ERR_NAMES = {-1: "ZK_ERR_INVALID", -2: "ZK_ERR_HIP", -3: "ZK_ERR_NOMEM", -4: "ZK_ERR_STATE",
+             -5: "ZK_ERR_BUFFER", -6: "ZK_ERR_VERIFY", -7: "ZK_ERR_CHECK"}
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class TranscriptInfo(C.Structure):
+    _fields_ = [("alpha_raw", C.c_uint32 * 3), ("beta_raw", C.c_uint32 * 32), ("free_term", C.c_uint32),
+                ("query_raw", C.c_uint32), ("public_last", C.c_uint32), ("roots", (C.c_uint8 * 32) * 34)]
+
+
+# name -> (restype, argtypes); every symbol include/zkstark_amd.h declares
+_u32, _sz, _vp, _int, _dbl = C.c_uint32, C.c_size_t, C.c_void_p, C.c_int, C.c_double
+_cp = C.c_char_p
+SYMBOLS = {
+    "zk_last_error": (_cp, []),
+    "zk_version": (_cp, []),
+    "zk_field_add": (_u32, [_u32, _u32]),
+    "zk_field_sub": (_u32, [_u32, _u32]),
+    "zk_field_mul": (_u32, [_u32, _u32]),
+    "zk_field_neg": (_u32, [_u32]),
+    "zk_field_inv": (_u32, [_u32]),
+    "zk_field_pow": (_u32, [_u32, _u32]),
+    "zk_field_from_u32": (_u32, [_u32]),
+    "zk_field_generator": (_u32, []),
+    "zk_field_root_of_unity": (_u32, [_u32]),
+    "zk_ctx_create": (_int, [_int, _u32, _u32, C.POINTER(_vp)]),
+    "zk_ctx_destroy": (_int, [_vp]),
+    "zk_ctx_setup_ms": (_dbl, [_vp]),
+    "zk_ctx_device_bytes": (_sz, [_vp]),
+    "zk_ctx_sync": (_int, [_vp]),
+    "zk_ctx_stream": (_vp, [_vp]),
+    "zk_ctx_set_profiling": (_int, [_vp, _int]),
+    "zk_trace_fibsq": (_int, [_u32, _u32, _sz, _vp]),
+    "zk_trace_upload": (_int, [_vp, _vp, _sz]),
+    "zk_lde": (_int, [_vp]),
+    "zk_merkle_commit": (_int, [_vp, _u32, _vp]),
+    "zk_compose": (_int, [_vp, _vp]),
+    "zk_fri_fold": (_int, [_vp, _u32, _u32]),
+    "zk_layer_read": (_int, [_vp, _u32, _sz, _sz, _vp]),
+    "zk_layer_write": (_int, [_vp, _u32, _sz, _sz, _vp]),
+    "zk_merkle_node": (_int, [_vp, _u32, _sz, _vp]),
+    "zk_merkle_path": (_int, [_vp, _u32, _sz, _vp, C.POINTER(_sz)]),
+    "zk_prove_resident": (_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "zk_prove": (_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
+    "zk_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
+    "zk_last_stage_ms": (_int, [_vp, C.POINTER(_dbl * 5)]),
+    "zk_verify": (_int, [_vp, _sz, _u32, _u32, _u32]),
+    "zk_proof_size": (_sz, [_sz]),
+    "zk_proof_data_len": (_sz, [_u32, _u32]),
+    "zk_compute_root_from_path": (_int, [_u32, _sz, _vp, _sz, _vp]),
+    "zk_channel_new": (_int, [C.POINTER(_vp)]),
+    "zk_channel_free": (_int, [_vp]),
+    "zk_channel_commit": (_int, [_vp, _vp, _sz]),
+    "zk_channel_get_u32": (_int, [_vp, C.POINTER(_u32)]),
+    "zk_channel_state": (_int, [_vp, _vp]),
+    "zk_channel_data_len": (_sz, [_vp]),
+    "zk_channel_data": (_int, [_vp, _vp, _sz]),
+    "zk_merkle_build_host": (_int, [_int, _vp, _sz, _vp]),
+    "zk_ntt_host": (_int, [_int, _vp, _u32, _int]),
+    "zk_lde_host": (_int, [_int, _vp, _u32, _u32, _vp]),
+    "zk_dev_merkle_build": (_int, [_vp, _u32, _vp, _vp]),
+    "zk_dev_merkle_node": (_int, [_vp, _sz, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded CDLL; builds it first if hipcc is present and the .so is stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        _build.build()
+    except Exception as e:  # no hipcc on this box: use the prebuilt .so that travelled with the repo
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"libzkstark_amd.so is missing and cannot be built: {e}") from e
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libzkstark_amd.so is missing: run `python -m zkstark_amd.build` (needs hipcc)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != ZK_OK:
+        raise ZkError(code, load().zk_last_error().decode())
+    return code

@@ -1,0 +1,79 @@
+// field.hpp -- arithmetic in GF(P), P = 3*2^30 + 1 = 3221225473, shared by host and device code.
+//
+// Replaces the reference's Gf<P> newtype over num_modular::MontgomeryInt<u32>
+// (field.rs:8-211, modulus at main.rs:13).  As in the reference the internal
+// Montgomery form is not observable: only canonical residues in [0, P) are
+// ever stored in HBM or cross the C ABI (Merkle leaves hash residue(),
+// prover.rs:81).
+//
+// Representation choice for gfx950.  P > 2^31, so a + b overflows u32 and there
+// is no lazy-reduction headroom; every add/sub is fully reduced with a
+// carry/borrow select.  Multiplication is Montgomery with R = 2^32, and the
+// shape of P makes the reduction cheap: P^-1 mod 2^32 = 2^30 + 1, so
+// m = lo * P^-1 is one shift-add, leaving three 32x32 multiplies per product
+// (lo, hi of a*b and hi of m*P).
+//
+// Convention used by every kernel: bulk data (trace, evaluations, FRI layers)
+// is stored as CANONICAL residues; constants and twiddles are stored in
+// MONTGOMERY form (x*R mod P).  mont_mul(canonical, montgomery) = canonical, so
+// butterflies and scalings never convert the data.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZK_HD __host__ __device__ __forceinline__
+#else
+#define ZK_HD inline
+#endif
+
+namespace zk {
+
+constexpr uint32_t P = 3221225473u;        // main.rs:13
+constexpr uint32_t P_INV = 0x40000001u;    // P * P_INV == 1 (mod 2^32)
+constexpr uint32_t R1 = 1073741823u;       // 2^32 mod P   (Montgomery form of 1)
+constexpr uint32_t GEN_W = 5u;             // smallest primitive root (field.rs:52-86, prover.rs:44)
+
+// field.rs:99-111
+ZK_HD uint32_t add(uint32_t a, uint32_t b) {
+    uint32_t nb = P - b;            // in (0, P]
+    uint32_t d = a - nb;            // a + b - P (mod 2^32)
+    return a < nb ? d + P : d;      // a + b < P  ->  a + b
+}
+// field.rs:113-132
+ZK_HD uint32_t sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    return a < b ? d + P : d;
+}
+// field.rs:198-203
+ZK_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+
+// Montgomery product a*b*R^-1 mod P, result canonical in [0, P).
+// Requires a*b < P*2^32, i.e. at least one operand < P (the other may be any u32,
+// which is how raw u32 challenges >= P are absorbed: field.rs:20-24).
+ZK_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b;
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo + (lo << 30);                           // lo * P_INV mod 2^32
+    uint32_t mp_hi = (uint32_t)(((uint64_t)m * P) >> 32);   // low words of t and m*P are equal
+    uint32_t r = hi - mp_hi;
+    return hi < mp_hi ? r + P : r;
+}
+
+// Host-side helpers (setup, verifier, scalar API).  Plain residues in and out.
+inline uint32_t mulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); }
+inline uint32_t powmod(uint32_t a, uint64_t e) {    // field.rs:26-38
+    uint32_t r = 1, b = a % P;
+    while (e) {
+        if (e & 1) r = mulmod(r, b);
+        b = mulmod(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+inline uint32_t invmod(uint32_t a) { return powmod(a, P - 2); }            // field.rs:205-210
+inline uint32_t to_mont(uint32_t a) { return (uint32_t)((((uint64_t)(a % P)) << 32) % P); }
+// generator of the multiplicative subgroup of order 2^log_order: w^((P-1)/2^log_order)
+// (prover.rs:48-49: exponents 3145728 and 393216 for orders 1024 and 8192)
+inline uint32_t root_of_unity(uint32_t log_order) { return powmod(GEN_W, (uint64_t)(P - 1) >> log_order); }
+
+}  // namespace zk

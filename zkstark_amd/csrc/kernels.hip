@@ -1,0 +1,469 @@
+// kernels.hip -- hand-written gfx950 kernels for the STARK-101 prover hot path.
+//
+//   ntt_pass_kernel      LDS-tiled radix-2^k NTT passes (replaces polynomial.rs:337-383 lagrange
+//                        and polynomial.rs:49-56 solve as used at prover.rs:60-70)
+//   compose_kernel       pointwise constraint composition (prover.rs:101-173)
+//   fri_fold_kernel      evaluation-form FRI fold (polynomial.rs:385-400 + prover.rs:204-211)
+//   merkle_*_kernel      SHA-256 Merkle heap (merkle.rs:14-51)
+//   gather_kernel        decommitment gather (merkle.rs:54-71, prover.rs:266-289)
+//
+// All bulk data is canonical u32 residues; all constants are in Montgomery form (field.hpp).
+// No MFMA anywhere: butterflies and SHA rounds are not a dense contraction.
+#include "kernels.hpp"
+
+#include "field.hpp"
+#include "sha256.hpp"
+
+namespace zk {
+
+__device__ __forceinline__ uint32_t pow_lookup(const PowTable& t, uint32_t e) {
+    return mont_mul(t.hi[e >> t.lo_bits], t.lo[e & ((1u << t.lo_bits) - 1u)]);
+}
+
+// Montgomery-domain inverse by Fermat: a^(P-2), P-2 = 0xBFFFFFFF.
+__device__ uint32_t mont_inv(uint32_t a) {
+    uint32_t r = R1, b = a;
+    uint32_t e = P - 2;
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) {
+        if (e & 1) r = mont_mul(r, b);
+        b = mont_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+// ===========================================================================
+// NTT passes
+// ===========================================================================
+//
+// The array is viewed as [A][R][S] with S fastest.  A workgroup owns a tile of C
+// columns (a, s) and all R rows t of those columns, stages it in LDS with row
+// pitch C+1, runs the log2(R) radix-2 stages there and writes the tile back in
+// place.  Global accesses are rows of C contiguous words (C*4 >= 128 B whenever
+// S >= 32), or one fully contiguous block when S < C.
+//
+// Inverse transforms run decimation-in-frequency (natural -> digit-reversed
+// order), forward transforms decimation-in-time (digit-reversed -> natural), with
+// the same radix list, so iNTT followed by NTT never needs a permutation pass.
+// Bit reversal inside one radix-R block is absorbed into the LDS row index.
+
+constexpr int kNttThreads = 256;
+
+__device__ __forceinline__ void tile_coords(uint32_t l, uint32_t logR, uint32_t logS, uint32_t logC,
+                                            uint32_t& t, uint32_t& c) {
+    if (logS >= logC) {            // row of C contiguous words
+        t = l >> logC;
+        c = l & ((1u << logC) - 1u);
+    } else {                       // whole tile is one contiguous block
+        uint32_t s = l & ((1u << logS) - 1u);
+        t = (l >> logS) & ((1u << logR) - 1u);
+        c = ((l >> (logR + logS)) << logS) | s;
+    }
+}
+
+template <uint32_t MODE>
+__global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(NttPassArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t logR = p.logR, logS = p.logS, logC = p.logC;
+    const uint32_t R = 1u << logR, C = 1u << logC, pitch = C + 1u;
+    uint32_t* tile = smem;              // R * pitch words
+    uint32_t* twl = smem + R * pitch;   // R/2 twiddles w_R^j
+    const uint32_t tid = threadIdx.x;
+    const uint32_t col0 = blockIdx.x << logC;
+    const uint32_t tile_elems = R << logC;
+    const uint32_t tw_shift = p.L - logR - logS;   // w_{RS} = root^(1 << tw_shift)
+    const uint32_t smask = (1u << logS) - 1u;
+
+    for (uint32_t j = tid; j < (R >> 1); j += kNttThreads) twl[j] = pow_lookup(p.tw, j << (p.L - logR));
+
+    // ---- load ---------------------------------------------------------------
+    if (MODE == NTT_DIT_LDE) {
+        // S = B.  Each coefficient feeds B columns: the innermost radix-B stage of the
+        // size-N transform sees (c, 0, ..., 0) and is a replication.  The coefficient is
+        // first corrected for the virtual last trace point (DESIGN.md "LDE"), then scaled
+        // by w^k / n (coset shift, prover.rs:69, and the iNTT normalisation).
+        const uint32_t logB = logS, n = 1u << p.log_n;
+        const uint32_t c_top = p.src[n - 1u];
+        const uint32_t a0 = col0 >> logB;
+        for (uint32_t u = tid; u < (tile_elems >> logB); u += kNttThreads) {
+            uint32_t ao = u >> logR, t = u & (R - 1u);
+            uint32_t pos = ((a0 + ao) << logR) | t;
+            uint32_t k = 0, rem = p.log_n, sh = 0;
+            for (uint32_t d = 0; d < p.nd; ++d) {
+                rem -= p.dig_bits[d];
+                k |= ((pos >> rem) & ((1u << p.dig_bits[d]) - 1u)) << sh;
+                sh += p.dig_bits[d];
+            }
+            uint32_t v = p.src[pos];
+            v = sub(v, mont_mul(c_top, pow_lookup(p.tw, ((k + 1u) & (n - 1u)) << logB)));
+            v = mont_mul(v, mont_mul(pow_lookup(p.wtab, k), p.ninv_mont));
+            uint32_t row = __brev(t) >> (32u - logR);
+            uint32_t* dstp = &tile[row * pitch + (ao << logB)];
+            dstp[0] = v;
+            for (uint32_t s = 1; s <= smask; ++s) dstp[s] = mont_mul(v, pow_lookup(p.tw, (t * s) << tw_shift));
+        }
+    } else {
+        for (uint32_t l = tid; l < tile_elems; l += kNttThreads) {
+            uint32_t t, c;
+            tile_coords(l, logR, logS, logC, t, c);
+            uint32_t col = col0 + c, a = col >> logS, s = col & smask;
+            size_t addr = ((size_t)a << (logR + logS)) | ((size_t)t << logS) | s;
+            uint32_t v = p.src[addr];
+            uint32_t row = t;
+            if (MODE == NTT_DIT) {
+                if (logS) v = mont_mul(v, pow_lookup(p.tw, (t * s) << tw_shift));
+                row = __brev(t) >> (32u - logR);
+            }
+            tile[row * pitch + c] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- log2(R) radix-2 stages in LDS ------------------------------------------
+    const uint32_t nb = tile_elems >> 1;
+    if (MODE == NTT_DIF) {   // Gentleman-Sande: natural in, bit-reversed out
+        for (int ll = (int)logR - 1; ll >= 0; --ll) {
+            for (uint32_t b = tid; b < nb; b += kNttThreads) {
+                uint32_t c = b & (C - 1u), pi = b >> logC;
+                uint32_t j = pi & ((1u << ll) - 1u);
+                uint32_t i = ((pi >> ll) << (ll + 1)) | j;
+                uint32_t* x0 = &tile[i * pitch + c];
+                uint32_t* x1 = x0 + (pitch << ll);
+                uint32_t u = *x0, v = *x1;
+                *x0 = add(u, v);
+                *x1 = mont_mul(sub(u, v), twl[j << (logR - 1u - ll)]);
+            }
+            __syncthreads();
+        }
+    } else {                 // Cooley-Tukey: bit-reversed in, natural out
+        for (uint32_t ll = 0; ll < logR; ++ll) {
+            for (uint32_t b = tid; b < nb; b += kNttThreads) {
+                uint32_t c = b & (C - 1u), pi = b >> logC;
+                uint32_t j = pi & ((1u << ll) - 1u);
+                uint32_t i = ((pi >> ll) << (ll + 1)) | j;
+                uint32_t* x0 = &tile[i * pitch + c];
+                uint32_t* x1 = x0 + (pitch << ll);
+                uint32_t u = *x0, v = mont_mul(*x1, twl[j << (logR - 1u - ll)]);
+                *x0 = add(u, v);
+                *x1 = sub(u, v);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- store --------------------------------------------------------------
+    for (uint32_t l = tid; l < tile_elems; l += kNttThreads) {
+        uint32_t t, c;
+        tile_coords(l, logR, logS, logC, t, c);
+        uint32_t col = col0 + c, a = col >> logS, s = col & smask;
+        size_t addr = ((size_t)a << (logR + logS)) | ((size_t)t << logS) | s;
+        uint32_t v;
+        if (MODE == NTT_DIF) {
+            v = tile[(__brev(t) >> (32u - logR)) * pitch + c];
+            if (logS) v = mont_mul(v, pow_lookup(p.tw, (t * s) << tw_shift));
+            else if (p.scale_mont) v = mont_mul(v, p.scale_mont);
+        } else {
+            v = tile[t * pitch + c];
+        }
+        p.dst[addr] = v;
+    }
+}
+
+hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s) {
+    uint32_t cols_log = a.log_total - a.logR;
+    uint32_t blocks = 1u << (cols_log - a.logC);
+    size_t shmem = ((size_t)(1u << a.logR) * ((1u << a.logC) + 1u) + (1u << a.logR) / 2u) * sizeof(uint32_t);
+    switch (mode) {
+        case NTT_DIF: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIF>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
+        case NTT_DIT: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
+        case NTT_DIT_LDE: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT_LDE>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+struct DigitArgs {
+    uint32_t nd;
+    uint32_t bits[kMaxDigits];
+};
+
+// to_natural: out[true_index(pos)] = in[pos]; else out[pos] = in[true_index(pos)]
+__global__ void digit_reverse_kernel(const uint32_t* in, uint32_t* out, uint32_t log_m, DigitArgs dg, int to_natural) {
+    size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= ((size_t)1 << log_m)) return;
+    uint32_t k = 0, rem = log_m, sh = 0;
+    for (uint32_t d = 0; d < dg.nd; ++d) {
+        rem -= dg.bits[d];
+        k |= (((uint32_t)pos >> rem) & ((1u << dg.bits[d]) - 1u)) << sh;
+        sh += dg.bits[d];
+    }
+    if (to_natural) out[k] = in[pos];
+    else out[pos] = in[k];
+}
+
+hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_m, uint32_t nd,
+                                const uint32_t* dig_bits, int to_natural, hipStream_t s) {
+    DigitArgs dg{};
+    dg.nd = nd;
+    for (uint32_t i = 0; i < nd; ++i) dg.bits[i] = dig_bits[i];
+    size_t m = (size_t)1 << log_m;
+    uint32_t threads = 256, blocks = (uint32_t)((m + threads - 1) / threads);
+    hipLaunchKernelGGL(digit_reverse_kernel, dim3(blocks), dim3(threads), 0, s, in, out, log_m, dg, to_natural);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Composition
+// ===========================================================================
+
+// Context setup: inv_xm1[i] = 1/(w h^i - 1), Montgomery form.  Each thread inverts
+// kInvBatch denominators with one Fermat inversion (Montgomery's trick).
+constexpr int kInvBatch = 8;
+
+__global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, uint32_t logN, PowTable htab) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t N = (size_t)1 << logN, base = gid * kInvBatch;
+    if (base >= N) return;
+    const uint32_t w_mont = (uint32_t)(((uint64_t)GEN_W << 32) % P);
+    uint32_t d[kInvBatch], pre[kInvBatch];
+    uint32_t acc = R1;
+#pragma unroll
+    for (int e = 0; e < kInvBatch; ++e) {
+        size_t i = base + e;
+        uint32_t x = i < N ? mont_mul(pow_lookup(htab, (uint32_t)i), w_mont) : add(R1, R1);
+        d[e] = sub(x, R1);
+        pre[e] = acc;
+        acc = mont_mul(acc, d[e]);
+    }
+    uint32_t inv = mont_inv(acc);
+#pragma unroll
+    for (int e = kInvBatch - 1; e >= 0; --e) {
+        size_t i = base + e;
+        uint32_t r = mont_mul(inv, pre[e]);
+        inv = mont_mul(inv, d[e]);
+        if (i < N) out[i] = r;
+    }
+}
+
+hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, hipStream_t s) {
+    size_t N = (size_t)1 << logN, threads_total = (N + kInvBatch - 1) / kInvBatch;
+    uint32_t blocks = (uint32_t)((threads_total + 255) / 256);
+    hipLaunchKernelGGL(build_inv_xm1_kernel, dim3(blocks), dim3(256), 0, s, out, logN, htab);
+    return hipGetLastError();
+}
+
+// cp(x_i) for x_i = w h^i (prover.rs:101-166 evaluated pointwise; the same formula the
+// verifier recomputes at proof.rs:63-77):
+//   p0 = (f(x) - a[0]) / (x - 1)
+//   p1 = (f(x) - a[n-2]) / (x - g^(n-2))            = (f(x) - a[n-2]) * g^2 / (x_{i+2B} - 1)
+//   p2 = (f(g^2 x) - f(g x)^2 - f(x)^2) (x - g^(n-3))(x - g^(n-2))(x - g^(n-1)) / (x^n - 1)
+//   cp = alpha0 p0 + alpha1 p1 + alpha2 p2
+// with f(g x_i) = f[i+B], f(g^2 x_i) = f[i+2B] (indices mod N); x^n - 1 depends on i mod B only.
+__global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
+    const size_t N = (size_t)1 << a.logN;
+    const uint32_t B = 1u << a.log_b;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const size_t i1 = (i + B) & (N - 1), i2 = (i + 2 * (size_t)B) & (N - 1);
+    uint32_t f0 = a.f[i], f1 = a.f[i1], f2 = a.f[i2];
+    uint32_t inv0 = a.inv_xm1[i], inv2 = a.inv_xm1[i2];
+    uint32_t x = mont_mul(pow_lookup(a.htab, (uint32_t)i), a.w_mont);           // Montgomery x_i
+    uint32_t t0 = mont_mul(mont_mul(sub(f0, a.first), inv0), a.alpha0_mont);
+    uint32_t t1 = mont_mul(mont_mul(sub(f0, a.last), inv2), a.alpha1g2_mont);
+    uint32_t v3 = mont_mul(mont_mul(sub(x, a.gm3_mont), sub(x, a.gm2_mont)), sub(x, a.gm1_mont));   // V*R
+    uint32_t y = mont_mul(v3, a.zz[i & (B - 1)]);                                // alpha2 V / (x^n-1) * R^2
+    // data*data products carry R^-1; bring f2 to the same scale, fix with the R^2 in y
+    uint32_t num = sub(sub(mont_mul(f2, 1u), mont_mul(f1, f1)), mont_mul(f0, f0));
+    uint32_t t2 = mont_mul(num, y);
+    a.cp[i] = add(add(t0, t1), t2);
+}
+
+hipError_t launch_compose(const ComposeArgs& a, hipStream_t s) {
+    size_t N = (size_t)1 << a.logN;
+    uint32_t blocks = (uint32_t)((N + 255) / 256);
+    hipLaunchKernelGGL(compose_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// FRI fold
+// ===========================================================================
+// next[i] = (e[i] + e[i+m/2])/2 + beta (e[i] - e[i+m/2]) / (2 x_i),  x_i = (w h^i)^(2^r)
+// (identity pinned by fri_test, polynomial.rs:418-425, and used at proof.rs:110-113).
+__global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a) {
+    const size_t half = (size_t)1 << (a.log_m - 1);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    uint32_t u = a.in[i], v = a.in[i + half];
+    uint32_t xinv = pow_lookup(a.hinv, (uint32_t)(i << a.round));   // h^(-2^r i), i 2^r < N/2
+    uint32_t s = mont_mul(add(u, v), a.inv2_mont);
+    uint32_t d = mont_mul(mont_mul(sub(u, v), xinv), a.c_mont);
+    a.out[i] = add(s, d);
+}
+
+hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s) {
+    size_t half = (size_t)1 << (a.log_m - 1);
+    uint32_t blocks = (uint32_t)((half + 255) / 256);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Merkle tree
+// ===========================================================================
+//
+// Heap layout of merkle.rs:14-51: 2m-1 nodes, root 0, children of j at 2j+1, 2j+2,
+// depth d occupies [2^d - 1, 2^(d+1) - 1), leaf i at m - 1 + i.
+//
+// SHA-256 is integer-VALU bound, so the design goal is 100 % lane utilisation and no
+// cross-lane traffic: a lane owns 2^k consecutive inputs and reduces that subtree
+// depth-first entirely in its own registers, with a k-entry digest stack in LDS.
+// All control flow is wave-uniform.  One launch lowers the tree by k levels; the last
+// <= 2^11 nodes are finished by a single workgroup that keeps the level in LDS.
+
+constexpr int kMerkleThreads = 256;
+constexpr uint32_t kMerkleMaxK = 4;
+constexpr uint32_t kMerkleTopLog = 11;   // the top kernel takes up to 2^11 inputs
+constexpr int kTopThreads = 1024;
+
+__device__ __forceinline__ void store_digest(uint32_t* nodes, size_t node, const Digest& d) {
+    uint4* q = reinterpret_cast<uint4*>(nodes + node * 8);
+    q[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+    q[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+}
+__device__ __forceinline__ Digest load_digest(const uint32_t* nodes, size_t node) {
+    const uint4* q = reinterpret_cast<const uint4*>(nodes + node * 8);
+    uint4 lo = q[0], hi = q[1];
+    Digest d;
+    d.w[0] = lo.x; d.w[1] = lo.y; d.w[2] = lo.z; d.w[3] = lo.w;
+    d.w[4] = hi.x; d.w[5] = hi.y; d.w[6] = hi.z; d.w[7] = hi.w;
+    return d;
+}
+
+template <bool LEAF>
+__global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const uint32_t* vals, uint32_t* nodes,
+                                                                        uint32_t depth_in, uint32_t k) {
+    extern __shared__ __attribute__((aligned(16))) uint4 stack[];   // [k][2][threads]
+    const uint32_t tid = threadIdx.x;
+    const size_t gid = (size_t)blockIdx.x * kMerkleThreads + tid;
+    if (gid >= ((size_t)1 << (depth_in - k))) return;   // no barriers below
+    const size_t base = gid << k;
+    const size_t in_base = ((size_t)1 << depth_in) - 1;
+#pragma unroll 1
+    for (uint32_t i = 0; i < (1u << k); ++i) {
+        Digest d;
+        if (LEAF) {
+            d = sha256_leaf(vals[base + i]);
+            store_digest(nodes, in_base + base + i, d);
+        } else {
+            d = load_digest(nodes, in_base + base + i);
+        }
+        uint32_t idx = i, lvl = 0;
+#pragma unroll 1
+        while (idx & 1u) {   // wave-uniform: i is the same in every lane
+            uint4 lo = stack[(lvl * 2 + 0) * kMerkleThreads + tid];
+            uint4 hi = stack[(lvl * 2 + 1) * kMerkleThreads + tid];
+            Digest l;
+            l.w[0] = lo.x; l.w[1] = lo.y; l.w[2] = lo.z; l.w[3] = lo.w;
+            l.w[4] = hi.x; l.w[5] = hi.y; l.w[6] = hi.z; l.w[7] = hi.w;
+            d = sha256_inner(l, d);
+            idx >>= 1;
+            ++lvl;
+            store_digest(nodes, (((size_t)1 << (depth_in - lvl)) - 1) + ((base + i) >> lvl), d);
+        }
+        if (lvl < k) {
+            stack[(lvl * 2 + 0) * kMerkleThreads + tid] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+            stack[(lvl * 2 + 1) * kMerkleThreads + tid] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+        }
+    }
+}
+
+// Finishes a tree whose level `depth_in` has <= 2^11 nodes: one workgroup, level kept in LDS.
+template <bool LEAF>
+__global__ __launch_bounds__(kTopThreads) void merkle_top_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^depth_in][2]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cnt = 1u << depth_in;
+    const size_t in_base = ((size_t)1 << depth_in) - 1;
+    for (uint32_t i = tid; i < cnt; i += kTopThreads) {
+        Digest d;
+        if (LEAF) {
+            d = sha256_leaf(vals[i]);
+            store_digest(nodes, in_base + i, d);
+        } else {
+            d = load_digest(nodes, in_base + i);
+        }
+        lvl[2 * i] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+        lvl[2 * i + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int dd = (int)depth_in - 1; dd >= 0; --dd) {
+        const uint32_t w = 1u << dd;
+        // w <= 1024 = kTopThreads: at most one node per thread per level
+        Digest d;
+        const bool active = tid < w;
+        if (active) {
+            uint4 a0 = lvl[4 * tid], a1 = lvl[4 * tid + 1], b0 = lvl[4 * tid + 2], b1 = lvl[4 * tid + 3];
+            Digest l, r;
+            l.w[0] = a0.x; l.w[1] = a0.y; l.w[2] = a0.z; l.w[3] = a0.w;
+            l.w[4] = a1.x; l.w[5] = a1.y; l.w[6] = a1.z; l.w[7] = a1.w;
+            r.w[0] = b0.x; r.w[1] = b0.y; r.w[2] = b0.z; r.w[3] = b0.w;
+            r.w[4] = b1.x; r.w[5] = b1.y; r.w[6] = b1.z; r.w[7] = b1.w;
+            d = sha256_inner(l, r);
+            store_digest(nodes, (((size_t)1 << dd) - 1) + tid, d);
+        }
+        __syncthreads();
+        if (active) {
+            lvl[2 * tid] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+            lvl[2 * tid + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s) {
+    uint32_t depth = log_m;
+    if (depth <= kMerkleTopLog) {
+        size_t sh = ((size_t)2 << depth) * sizeof(uint4);
+        hipLaunchKernelGGL(merkle_top_kernel<true>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
+        return hipGetLastError();
+    }
+    bool leaf = true;
+    while (depth > kMerkleTopLog) {
+        // keep >= 2^18 lanes in flight (256 CUs x 4 SIMDs x 64 lanes x 4 waves) while they last
+        uint32_t k = depth > 18 ? depth - 18 : 1;
+        if (k > kMerkleMaxK) k = kMerkleMaxK;
+        if (depth - k < kMerkleTopLog) k = depth - kMerkleTopLog;
+        size_t lanes = (size_t)1 << (depth - k);
+        uint32_t blocks = (uint32_t)((lanes + kMerkleThreads - 1) / kMerkleThreads);
+        size_t sh = (size_t)k * 2 * kMerkleThreads * sizeof(uint4);
+        if (leaf) hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+        else hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+        leaf = false;
+        depth -= k;
+    }
+    size_t sh = ((size_t)2 << depth) * sizeof(uint4);
+    hipLaunchKernelGGL(merkle_top_kernel<false>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Decommit gather
+// ===========================================================================
+__global__ void gather_kernel(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words, uint32_t* out) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * words) return;
+    uint32_t item = idx / words, w = idx % words;
+    out[idx] = src[offsets[item] + w];
+}
+
+hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
+                         uint32_t* out, hipStream_t s) {
+    if (!count) return hipSuccess;
+    uint32_t total = count * words, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, src, offsets, count, words, out);
+    return hipGetLastError();
+}
+
+}  // namespace zk

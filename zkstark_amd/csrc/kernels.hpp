@@ -1,0 +1,90 @@
+// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+// Everything here is stream-ordered and takes raw device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zk {
+
+// Two-level table of powers of a fixed root, entries in Montgomery form:
+//   root^e = hi[e >> lo_bits] * lo[e & ((1 << lo_bits) - 1)]
+// Both halves are a few KiB, so twiddles are served from L1/L2 instead of
+// streaming a full N-entry table from HBM.
+struct PowTable {
+    const uint32_t* lo;
+    const uint32_t* hi;
+    uint32_t lo_bits;
+};
+
+constexpr int kMaxDigits = 6;
+
+// One LDS-tiled radix-2^logR pass over an array viewed as [A][R][S] (S fastest).
+enum NttMode : uint32_t {
+    NTT_DIF = 0,        // natural in -> digit-reversed out; post-twiddle (inverse-transform passes)
+    NTT_DIT = 1,        // digit-reversed in -> natural out; pre-twiddle (forward passes)
+    NTT_DIT_LDE = 2,    // first forward pass of the LDE: reads n scaled coefficients, writes N = n*B values
+};
+
+struct NttPassArgs {
+    const uint32_t* src;
+    uint32_t* dst;
+    uint32_t log_total;   // log2 of the number of elements of dst
+    uint32_t logR, logS;  // this pass: radix and inner stride
+    uint32_t logC;        // columns per workgroup tile (tile = R * C elements)
+    uint32_t L;           // the table root has order 2^L
+    PowTable tw;          // h (forward) or h^-1 (inverse)
+    uint32_t scale_mont;  // NTT_DIF only: multiply outputs by this Montgomery constant when S == 1 (n^-1); 0 = none
+    // NTT_DIT_LDE only:
+    PowTable wtab;        // powers of the coset shift w
+    uint32_t log_n;       // coefficient count
+    uint32_t ninv_mont;   // n^-1 in Montgomery form
+    uint32_t nd;          // number of storage digits of the coefficient array, slowest first
+    uint32_t dig_bits[kMaxDigits];
+};
+
+hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s);
+// out[pos] = in[true_index(pos)] for the mixed-radix digit reversal (standalone NTT API only)
+hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_m, uint32_t nd,
+                                const uint32_t* dig_bits, int to_natural, hipStream_t s);
+
+// inv_xm1[i] = 1 / (w h^i - 1) in Montgomery form, i < N (context setup)
+hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, hipStream_t s);
+
+struct ComposeArgs {
+    const uint32_t* f;        // N canonical evaluations of the trace polynomial
+    const uint32_t* inv_xm1;  // N, Montgomery
+    uint32_t* cp;             // N out
+    uint32_t logN, log_b;
+    PowTable htab;
+    uint32_t w_mont;          // w
+    uint32_t gm1_mont, gm2_mont, gm3_mont;  // g^-1, g^-2, g^-3
+    uint32_t first;           // a[0] canonical
+    uint32_t last;            // a[n-2] canonical
+    uint32_t alpha0_mont;     // alpha0
+    uint32_t alpha1g2_mont;   // alpha1 * g^2
+    uint32_t zz[32];          // B entries: alpha2 / (x^n - 1) * R^2  (per i mod B)
+};
+hipError_t launch_compose(const ComposeArgs& a, hipStream_t s);
+
+struct FoldArgs {
+    const uint32_t* in;   // m values
+    uint32_t* out;        // m/2 values
+    uint32_t log_m;       // log2 m
+    uint32_t round;       // r: x_i = (w h^i)^(2^r)
+    PowTable hinv;        // h^-1 table, order 2^L
+    uint32_t L;
+    uint32_t inv2_mont;   // 1/2
+    uint32_t c_mont;      // beta * w^(-2^r) / 2
+};
+hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
+
+// Merkle tree over m = 2^log_m u32 leaves.  nodes: (2m-1) * 8 words, heap order
+// (merkle.rs:14-51), each node the eight SHA-256 state words.
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s);
+
+// out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
+hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
+                         uint32_t* out, hipStream_t s);
+
+}  // namespace zk

@@ -1,0 +1,146 @@
+// sha256.hpp -- SHA-256 (FIPS 180-4) for the Merkle commitment and the transcript.
+//
+// Replaces the `sha2` crate as used by merkle.rs:31-33, :42-45, :87-104 and
+// channel.rs:21-24.  Two block shapes exist on the device path
+// (SURVEY.md A.6):
+//   leaf : one block, W0 = value (u32.to_be_bytes() read as a big-endian word is the
+//          word itself, merkle.rs:32), W1 = 0x80000000, W15 = 32
+//   inner: block 1 = left || right (16 words), block 2 = constant padding
+//          (0x80000000, 0, ..., 512) whose whole message schedule folds at compile time.
+// Digests live in HBM as the eight big-endian STATE WORDS (native u32), so no byte
+// swaps occur between tree levels; bytes are produced only when a digest is
+// exported to the host (root, auth paths).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define ZK_SHA_HD __host__ __device__ __forceinline__
+#else
+#define ZK_SHA_HD inline
+#endif
+
+namespace zk {
+
+struct Digest {
+    uint32_t w[8];
+};
+
+constexpr uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+ZK_SHA_HD uint32_t sha_rotr(uint32_t x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(x, x, n);   // v_alignbit_b32
+#else
+    return (x >> n) | (x << (32 - n));
+#endif
+}
+
+constexpr uint32_t SHA_IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                                0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+
+// One compression, fully unrolled with a rolling 16-word schedule.  Every call
+// site is inlined, so constant message words / constant chaining values fold away.
+ZK_SHA_HD void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        uint32_t wi;
+        if (i < 16) {
+            wi = w[i];
+        } else {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            w[i & 15] = wi;
+        }
+        uint32_t S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = h + S1 + ch + SHA_K[i] + wi;
+        uint32_t S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
+        uint32_t mj = ((a ^ b) & c) | (~(a ^ b) & b);   // == maj(a,b,c), one v_bfi_b32
+        uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+// merkle.rs:30-34: SHA256(v.to_be_bytes())
+ZK_SHA_HD Digest sha256_leaf(uint32_t v) {
+    uint32_t w[16] = {v, 0x80000000u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32u};
+    Digest d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d.w[i] = SHA_IV[i];
+    sha256_compress(d.w, w);
+    return d;
+}
+
+// merkle.rs:42-45: SHA256(left || right)
+ZK_SHA_HD Digest sha256_inner(const Digest& l, const Digest& r) {
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w[i] = l.w[i]; w[8 + i] = r.w[i]; }
+    Digest d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d.w[i] = SHA_IV[i];
+    sha256_compress(d.w, w);
+    uint32_t pad[16] = {0x80000000u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 512u};
+    sha256_compress(d.w, pad);
+    return d;
+}
+
+// ---- host-only generic hashing (transcript, verifier) ---------------------
+struct Sha256 {
+    uint32_t st[8];
+    uint8_t buf[64];
+    size_t fill = 0;
+    uint64_t total = 0;
+    Sha256() { for (int i = 0; i < 8; ++i) st[i] = SHA_IV[i]; }
+    void block(const uint8_t* p) {
+        uint32_t w[16];
+        for (int i = 0; i < 16; ++i)
+            w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+        sha256_compress(st, w);
+    }
+    void update(const void* data, size_t n) {
+        const uint8_t* m = (const uint8_t*)data;
+        total += n;
+        while (n) {
+            size_t take = 64 - fill < n ? 64 - fill : n;
+            memcpy(buf + fill, m, take);
+            fill += take; m += take; n -= take;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    void finalize(uint8_t out[32]) {
+        uint64_t bits = total * 8;
+        uint8_t pad[72] = {0x80};
+        size_t padlen = (fill < 56 ? 56 - fill : 120 - fill);
+        update(pad, padlen);
+        uint8_t len[8];
+        for (int i = 0; i < 8; ++i) len[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(len, 8);
+        for (int i = 0; i < 8; ++i) {
+            out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+            out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
+        }
+    }
+};
+// digest state words -> the 32 bytes the reference's Hash = [u8; 32] holds (merkle.rs:9)
+inline void digest_words_to_bytes(const uint32_t w[8], uint8_t out[32]) {
+    for (int i = 0; i < 8; ++i) {
+        out[4 * i] = (uint8_t)(w[i] >> 24); out[4 * i + 1] = (uint8_t)(w[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(w[i] >> 8); out[4 * i + 3] = (uint8_t)w[i];
+    }
+}
+
+}  // namespace zk

@@ -1,0 +1,169 @@
+// transcript.hpp -- host-only Fiat-Shamir channel, proof wire format and verifier.
+//
+// Channel mirrors channel.rs:6-37; the byte encoding is bincode 1.x defaults
+// (little-endian fixed-width ints, [u8;32] raw, Box<[T]> = u64 count + items)
+// as read back by proof.rs:16-46.  The reference holds no golden bytes for the
+// transcript, so this encoding is "parity unpinned" (SURVEY.md section 8c).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "field.hpp"
+#include "sha256.hpp"
+
+namespace zk {
+
+struct Channel {
+    uint8_t state[32];
+    std::vector<uint8_t> data;
+    Channel() { memset(state, 0, 32); }   // channel.rs:12-17
+    // channel.rs:19-26
+    void commit_bytes(const uint8_t* b, size_t n) {
+        Sha256 h;
+        h.update(state, 32);
+        h.update(b, n);
+        h.finalize(state);
+        data.insert(data.end(), b, b + n);
+    }
+    void commit_hash(const uint8_t h[32]) { commit_bytes(h, 32); }
+    void commit_u32(uint32_t v) {
+        uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)};
+        commit_bytes(b, 4);
+    }
+    // channel.rs:28-32
+    uint32_t get_u32() {
+        uint32_t f = ((uint32_t)state[0] << 24) | ((uint32_t)state[1] << 16) | ((uint32_t)state[2] << 8) | state[3];
+        commit_u32(f);
+        return f;
+    }
+    static void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+    static void put64(std::vector<uint8_t>& v, uint64_t x) { for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+    // (u32, AuthPath): prover.rs:274-277
+    void commit_val_path(uint32_t val, const uint8_t* path, size_t plen) {
+        std::vector<uint8_t> b;
+        put32(b, val); put64(b, plen);
+        b.insert(b.end(), path, path + 32 * plen);
+        commit_bytes(b.data(), b.size());
+    }
+    // (u32, u32, AuthPath, AuthPath): prover.rs:288
+    void commit_pair_paths(uint32_t v0, uint32_t v1, const uint8_t* p0, const uint8_t* p1, size_t plen) {
+        std::vector<uint8_t> b;
+        put32(b, v0); put32(b, v1);
+        put64(b, plen); b.insert(b.end(), p0, p0 + 32 * plen);
+        put64(b, plen); b.insert(b.end(), p1, p1 + 32 * plen);
+        commit_bytes(b.data(), b.size());
+    }
+};
+
+inline size_t proof_data_len(uint32_t log_n, uint32_t log_b) {
+    size_t L = log_n + log_b, R = log_n;
+    size_t len = 32 + 12 + 32 + R * 36 + 4 + 4 + 4 * (4 + 8 + 32 * L);
+    for (size_t i = 0; i < R; ++i) len += 8 + 2 * (8 + 32 * (L - i));
+    return len;
+}
+
+// merkle.rs:82-110
+inline void compute_root_from_path(uint32_t element, size_t index, const uint8_t* path, size_t plen, uint8_t out[32]) {
+    index += ((size_t)1 << plen) - 1;
+    uint8_t cur[32];
+    {
+        uint8_t be[4] = {(uint8_t)(element >> 24), (uint8_t)(element >> 16), (uint8_t)(element >> 8), (uint8_t)element};
+        Sha256 h; h.update(be, 4); h.finalize(cur);
+    }
+    for (size_t k = 0; k < plen; ++k) {
+        Sha256 h;
+        if (index % 2 == 0) { h.update(path + 32 * k, 32); h.update(cur, 32); index -= 2; }
+        else { h.update(cur, 32); h.update(path + 32 * k, 32); index -= 1; }
+        h.finalize(cur);
+        index >>= 1;
+    }
+    memcpy(out, cur, 32);
+}
+
+// proof.rs:15-149 with the literals generalised.  Returns 0 or the negative index of the failed check.
+inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last) {
+    if (log_n < 2 || log_b < 1 || log_n + log_b > 30) return -1;
+    const size_t n = (size_t)1 << log_n, B = (size_t)1 << log_b, N = n << log_b, R = log_n, L = log_n + log_b;
+    const uint8_t* p = data;
+    size_t left = len;
+    bool bad = false;
+    auto take = [&](size_t k) -> const uint8_t* {
+        if (left < k) { bad = true; return nullptr; }
+        const uint8_t* q = p; p += k; left -= k; return q;
+    };
+    auto take32 = [&]() -> uint32_t {
+        const uint8_t* q = take(4);
+        return q ? ((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24)) : 0;
+    };
+    auto take_path = [&](size_t& plen) -> const uint8_t* {
+        const uint8_t* q = take(8);
+        if (!q) return nullptr;
+        uint64_t c = 0;
+        for (int i = 0; i < 8; ++i) c |= (uint64_t)q[i] << (8 * i);
+        if (c > 64) { bad = true; return nullptr; }
+        plen = (size_t)c;
+        return take(32 * plen);
+    };
+    // proof.rs:20-46
+    const uint8_t* f_root = take(32);
+    uint32_t alpha[3] = {take32(), take32(), take32()};
+    const uint8_t* roots[40]; uint32_t betas[40];
+    roots[0] = take(32); betas[0] = 0;
+    for (size_t i = 0; i < R; ++i) { betas[i + 1] = take32(); roots[i + 1] = take(32); }
+    uint32_t free_term = take32(), test_raw = take32();
+    uint32_t fv[4]; const uint8_t* fp[4]; size_t fpl[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) { fv[i] = take32(); fp[i] = take_path(fpl[i]); }
+    uint32_t lx[40], lnx[40]; const uint8_t *lpx[40], *lpnx[40]; size_t plx[40], plnx[40];
+    for (size_t i = 0; i < R; ++i) {
+        lx[i] = take32(); lnx[i] = take32(); plx[i] = plnx[i] = 0;
+        lpx[i] = take_path(plx[i]); lpnx[i] = take_path(plnx[i]);
+    }
+    if (bad) return -1;
+    // proof.rs:49-60
+    const uint32_t g = root_of_unity(log_n), h = root_of_unity((uint32_t)L);
+    const size_t tp = (size_t)test_raw % (N - 2 * B);
+    const uint32_t x = mulmod(GEN_W, powmod(h, tp));
+    auto fsub = [](uint32_t a, uint32_t b) { return sub(a, b); };
+    {   // proof.rs:63-77
+        uint32_t f_x = fv[0] % P, f_gx = fv[1] % P, f_ggx = fv[2] % P;
+        uint32_t gm1 = invmod(g), gm2 = mulmod(gm1, gm1), gm3 = mulmod(gm2, gm1);
+        uint32_t p0 = mulmod(fsub(f_x, 1), invmod(fsub(x, 1)));
+        uint32_t p1 = mulmod(fsub(f_x, public_last % P), invmod(fsub(x, gm2)));
+        uint32_t num = fsub(fsub(f_ggx, mulmod(f_gx, f_gx)), mulmod(f_x, f_x));
+        uint32_t den = mulmod(fsub(powmod(x, n), 1), invmod(mulmod(mulmod(fsub(x, gm3), fsub(x, gm2)), fsub(x, gm1))));
+        uint32_t p2 = mulmod(num, invmod(den));
+        uint32_t cp0 = add(add(mulmod(alpha[0] % P, p0), mulmod(alpha[1] % P, p1)), mulmod(alpha[2] % P, p2));
+        if (cp0 != fv[3]) return -2;
+    }
+    uint8_t root[32];
+    if (fpl[0] != L || fpl[1] != L || fpl[2] != L || fpl[3] != L) return -3;
+    // proof.rs:80-95
+    compute_root_from_path(fv[0], tp, fp[0], fpl[0], root);         if (memcmp(root, f_root, 32)) return -4;
+    compute_root_from_path(fv[1], tp + B, fp[1], fpl[1], root);     if (memcmp(root, f_root, 32)) return -5;
+    compute_root_from_path(fv[2], tp + 2 * B, fp[2], fpl[2], root); if (memcmp(root, f_root, 32)) return -6;
+    compute_root_from_path(fv[3], tp, fp[3], fpl[3], root);         if (memcmp(root, roots[0], 32)) return -7;
+    // proof.rs:101-126
+    const uint32_t inv2 = invmod(2);
+    for (size_t k = 0; k < R; ++k) {
+        uint32_t xk = powmod(x, (uint64_t)1 << k);
+        uint32_t gx = mulmod(add(lx[k] % P, lnx[k] % P), inv2);
+        uint32_t hx = mulmod(fsub(lx[k] % P, lnx[k] % P), invmod(mulmod(xk, 2)));
+        uint32_t calc = add(gx, mulmod(betas[k + 1] % P, hx));
+        uint32_t expect = (k + 1 < R) ? lx[k + 1] : free_term;
+        if (calc != expect) return -(int)(100 + k);
+    }
+    // proof.rs:129-148
+    for (size_t k = 0; k < R; ++k) {
+        size_t size = N >> k;
+        if (plx[k] != L - k || plnx[k] != L - k) return -(int)(200 + k);
+        compute_root_from_path(lx[k], tp % size, lpx[k], plx[k], root);
+        if (memcmp(root, roots[k], 32)) return -(int)(300 + k);
+        compute_root_from_path(lnx[k], (tp + size / 2) % size, lpnx[k], plnx[k], root);
+        if (memcmp(root, roots[k], 32)) return -(int)(400 + k);
+    }
+    return 0;
+}
+
+}  // namespace zk

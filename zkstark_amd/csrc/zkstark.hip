@@ -1,0 +1,787 @@
+// zkstark.hip -- context, pipeline stages, host prover and the C ABI (include/zkstark_amd.h).
+//
+// Host orchestration of prover.rs:9-293 re-written around device-resident data:
+// everything between "trace on device" and "proof bytes on host" stays in HBM;
+// per commitment one 32-byte root comes back and one 4-byte challenge goes out.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zkstark_amd.h"
+#include "field.hpp"
+#include "kernels.hpp"
+#include "sha256.hpp"
+#include "transcript.hpp"
+
+using namespace zk;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- transform plan ----------------------------------------------------------
+// The size-2^log_m transform is split into radix-2^bits[d] passes, d = 0 slowest
+// storage digit.  DIF (inverse) runs d = 0 .. nd-1, DIT (forward) nd-1 .. 0.
+constexpr uint32_t kTileLog = 13;      // 8192 words = 32 KiB per workgroup tile
+constexpr uint32_t kMaxRadixLog = 8;
+
+struct Plan {
+    uint32_t nd = 0;
+    uint32_t bits[kMaxDigits] = {0};
+};
+
+Plan make_plan(uint32_t log_m) {
+    Plan p;
+    uint32_t np = (log_m + kMaxRadixLog - 1) / kMaxRadixLog;
+    if (np == 0) np = 1;
+    uint32_t base = log_m / np, extra = log_m % np;
+    p.nd = np;
+    for (uint32_t d = 0; d < np; ++d) p.bits[d] = base + (d < extra ? 1 : 0);
+    return p;
+}
+
+uint32_t pick_logC(uint32_t log_total, uint32_t logR) {
+    uint32_t cols = log_total - logR, cap = kTileLog - logR;
+    return cols < cap ? cols : cap;
+}
+
+// ---- power tables --------------------------------------------------------------
+struct DevTable {
+    uint32_t* lo = nullptr;
+    uint32_t* hi = nullptr;
+    uint32_t lo_bits = 0;
+    PowTable view() const { return PowTable{lo, hi, lo_bits}; }
+};
+
+int build_table(uint32_t root, uint32_t log_order, DevTable* t) {
+    uint32_t lo_bits = (log_order + 1) / 2, hi_bits = log_order - lo_bits;
+    std::vector<uint32_t> lo((size_t)1 << lo_bits), hi((size_t)1 << hi_bits);
+    uint32_t acc = 1;
+    for (size_t j = 0; j < lo.size(); ++j) { lo[j] = to_mont(acc); acc = mulmod(acc, root); }
+    uint32_t step = powmod(root, (uint64_t)1 << lo_bits);
+    acc = 1;
+    for (size_t j = 0; j < hi.size(); ++j) { hi[j] = to_mont(acc); acc = mulmod(acc, step); }
+    HIPCHK(hipMalloc(&t->lo, lo.size() * 4));
+    HIPCHK(hipMalloc(&t->hi, hi.size() * 4));
+    HIPCHK(hipMemcpy(t->lo, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->hi, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+    t->lo_bits = lo_bits;
+    return ZK_OK;
+}
+void free_table(DevTable* t) {
+    if (t->lo) (void)hipFree(t->lo);
+    if (t->hi) (void)hipFree(t->hi);
+    t->lo = t->hi = nullptr;
+}
+
+// Inverse transform, natural order in, digit-reversed out, optionally scaled by scale_mont.
+int run_dif(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw_inv, uint32_t L, uint32_t scale_mont, hipStream_t s) {
+    uint32_t inner = log_m;
+    for (uint32_t d = 0; d < pl.nd; ++d) {
+        inner -= pl.bits[d];
+        NttPassArgs a{};
+        a.src = data; a.dst = data; a.log_total = log_m;
+        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR);
+        a.L = L; a.tw = tw_inv; a.scale_mont = (inner == 0) ? scale_mont : 0;
+        HIPCHK(launch_ntt_pass(a, NTT_DIF, s));
+    }
+    return ZK_OK;
+}
+// Forward transform, digit-reversed in, natural out.
+int run_dit(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw, uint32_t L, hipStream_t s) {
+    uint32_t inner = 0;
+    for (int d = (int)pl.nd - 1; d >= 0; --d) {
+        NttPassArgs a{};
+        a.src = data; a.dst = data; a.log_total = log_m;
+        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR);
+        a.L = L; a.tw = tw;
+        HIPCHK(launch_ntt_pass(a, NTT_DIT, s));
+        inner += pl.bits[d];
+    }
+    return ZK_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// Context
+// ===========================================================================
+struct zk_ctx {
+    int device = 0;
+    uint32_t log_n = 0, log_b = 0, L = 0;
+    size_t n = 0, N = 0, B = 0;
+    uint32_t R = 0;   // FRI rounds = log_n (prover.rs:198)
+    hipStream_t stream = nullptr;
+    DevTable H, Hinv, W;
+    uint32_t* d_inv_xm1 = nullptr;
+    Plan plan;
+    uint32_t* d_trace = nullptr;    // n words: trace, then coefficients (digit-reversed order)
+    uint32_t* d_layers = nullptr;   // layer 0 (N) | layer 1 (N) | layer 2 (N/2) | ... | layer R+1 (B)
+    std::vector<size_t> layer_off, layer_len;
+    uint32_t* d_trees = nullptr;    // tree t over layer t, (2m-1)*8 words each
+    std::vector<size_t> tree_off;
+    uint64_t* d_gather_off = nullptr;
+    uint32_t* d_gather_out = nullptr;
+    uint64_t* h_gather_off = nullptr;   // pinned
+    uint32_t* h_gather_out = nullptr;   // pinned
+    uint32_t* h_small = nullptr;        // pinned: root words + last layer
+    size_t gather_cap = 0;
+    size_t device_bytes = 0;
+    double setup_ms = 0;
+    // constants (Montgomery)
+    uint32_t w_mont = 0, gm1_mont = 0, gm2_mont = 0, gm3_mont = 0, ninv_mont = 0, inv2_mont = 0;
+    uint32_t g = 0, h = 0;
+    // per-proof state
+    bool have_trace = false, have_lde = false;
+    uint32_t first = 0, last = 0;
+    zk_transcript_info info{};
+    bool profiling = false;
+    double stage_ms[5] = {0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_stage;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(zk_ctx* c, T** p, size_t bytes) {
+    hipError_t e = hipMalloc((void**)p, bytes ? bytes : 4);
+    if (e != hipSuccess) return fail(ZK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    c->device_bytes += bytes;
+    return ZK_OK;
+}
+
+size_t layer_size(const zk_ctx* c, uint32_t layer) { return layer == 0 ? c->N : (c->N >> (layer - 1)); }
+uint32_t layer_log(const zk_ctx* c, uint32_t layer) { return layer == 0 ? c->L : c->L - (layer - 1); }
+
+struct StageTimer {
+    zk_ctx* c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(zk_ctx* c_, int st) : c(c_), stage(st) {
+        if (!c->profiling) return;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~StageTimer() {
+        if (!c->profiling) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ev.push_back(a); c->ev.push_back(b); c->ev_stage.push_back(stage);
+    }
+};
+
+void collect_stage_times(zk_ctx* c) {
+    for (int i = 0; i < 5; ++i) c->stage_ms[i] = 0;
+    for (size_t i = 0; i < c->ev_stage.size(); ++i) {
+        float ms = 0;
+        (void)hipEventSynchronize(c->ev[2 * i + 1]);
+        (void)hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]);
+        c->stage_ms[c->ev_stage[i]] += ms;
+        (void)hipEventDestroy(c->ev[2 * i]); (void)hipEventDestroy(c->ev[2 * i + 1]);
+    }
+    c->ev.clear(); c->ev_stage.clear();
+}
+
+int do_lde(zk_ctx* c) {
+    StageTimer tm(c, 0);
+    // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
+    int rc = run_dif(c->d_trace, c->log_n, c->plan, c->Hinv.view(), c->L, 0, c->stream);
+    if (rc) return rc;
+    // size-N forward transform of the zero-padded, w^k-scaled coefficients
+    uint32_t* f = c->d_layers + c->layer_off[0];
+    uint32_t inner = c->log_b;
+    for (int d = (int)c->plan.nd - 1; d >= 0; --d) {
+        NttPassArgs a{};
+        a.log_total = c->L; a.logR = c->plan.bits[d]; a.logS = inner; a.logC = pick_logC(c->L, a.logR);
+        a.L = c->L; a.tw = c->H.view();
+        a.dst = f;
+        if (d == (int)c->plan.nd - 1) {
+            if (a.logC < c->log_b) a.logC = c->log_b;
+            a.src = c->d_trace;
+            a.wtab = c->W.view(); a.log_n = c->log_n; a.ninv_mont = c->ninv_mont;
+            a.nd = c->plan.nd;
+            for (uint32_t q = 0; q < c->plan.nd; ++q) a.dig_bits[q] = c->plan.bits[q];
+            HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, c->stream));
+        } else {
+            a.src = f;
+            HIPCHK(launch_ntt_pass(a, NTT_DIT, c->stream));
+        }
+        inner += c->plan.bits[d];
+    }
+    c->have_lde = true;
+    return ZK_OK;
+}
+
+int do_merkle(zk_ctx* c, uint32_t layer) {
+    StageTimer tm(c, 1);
+    HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer),
+                               c->d_trees + c->tree_off[layer], c->stream));
+    return ZK_OK;
+}
+
+int do_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
+    StageTimer tm(c, 2);
+    ComposeArgs a{};
+    a.f = c->d_layers + c->layer_off[0];
+    a.inv_xm1 = c->d_inv_xm1;
+    a.cp = c->d_layers + c->layer_off[1];
+    a.logN = c->L; a.log_b = c->log_b;
+    a.htab = c->H.view();
+    a.w_mont = c->w_mont; a.gm1_mont = c->gm1_mont; a.gm2_mont = c->gm2_mont; a.gm3_mont = c->gm3_mont;
+    a.first = c->first; a.last = c->last;
+    uint32_t a0 = alpha_raw[0] % P, a1 = alpha_raw[1] % P, a2 = alpha_raw[2] % P;   // field.rs:20-24
+    a.alpha0_mont = to_mont(a0);
+    a.alpha1g2_mont = to_mont(mulmod(a1, mulmod(c->g, c->g)));
+    // x^n on the coset takes B values: (w h^i)^n = w^n (h^n)^(i mod B)
+    uint32_t xn = powmod(GEN_W, c->n), hn = powmod(c->h, c->n);
+    for (size_t r = 0; r < c->B; ++r) {
+        uint32_t zinv = invmod(sub(xn, 1));
+        a.zz[r] = to_mont(to_mont(mulmod(a2, zinv)));
+        xn = mulmod(xn, hn);
+    }
+    HIPCHK(launch_compose(a, c->stream));
+    return ZK_OK;
+}
+
+int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
+    StageTimer tm(c, 3);
+    FoldArgs a{};
+    a.in = c->d_layers + c->layer_off[1 + round];
+    a.out = c->d_layers + c->layer_off[2 + round];
+    a.log_m = c->L - round;
+    a.round = round;
+    a.hinv = c->Hinv.view();
+    a.L = c->L;
+    a.inv2_mont = c->inv2_mont;
+    uint32_t winv = invmod(powmod(GEN_W, (uint64_t)1 << round));
+    a.c_mont = to_mont(mulmod(mulmod(beta_raw % P, winv), invmod(2)));
+    HIPCHK(launch_fri_fold(a, c->stream));
+    return ZK_OK;
+}
+
+int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
+    HIPCHK(hipMemcpyAsync(c->h_small, c->d_trees + c->tree_off[tree], 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    digest_words_to_bytes(c->h_small, out);
+    return ZK_OK;
+}
+
+// merkle.rs:54-71: node indices of the authentication path of `leaf` in a tree of m leaves
+void path_nodes(size_t m, size_t leaf, std::vector<size_t>& out) {
+    size_t i = leaf + (2 * m - 1) / 2;
+    while (i != 0) {
+        if (i % 2 == 0) { out.push_back(i - 1); i -= 2; }
+        else { out.push_back(i + 1); i -= 1; }
+        i >>= 1;
+    }
+}
+
+int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]) {
+    if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_prove_resident: no trace uploaded");
+    const uint32_t R = c->R;
+    const size_t B = c->B, N = c->N;
+    Channel ch;                                          // main.rs:19
+    uint8_t root[32];
+    int rc;
+    memset(&c->info, 0, sizeof c->info);
+    c->info.public_last = c->last;
+    if ((rc = do_lde(c))) return rc;                      // prover.rs:60-70
+    if ((rc = do_merkle(c, 0))) return rc;                // prover.rs:81
+    if ((rc = read_root(c, 0, root))) return rc;
+    ch.commit_hash(root);                                 // prover.rs:85
+    memcpy(c->info.roots[0], root, 32);
+    uint32_t alpha[3];
+    for (int i = 0; i < 3; ++i) alpha[i] = c->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
+    if ((rc = do_compose(c, alpha))) return rc;           // prover.rs:166-173
+    if ((rc = do_merkle(c, 1))) return rc;                // prover.rs:176
+    if ((rc = read_root(c, 1, root))) return rc;
+    ch.commit_hash(root);                                 // prover.rs:180
+    memcpy(c->info.roots[1], root, 32);
+    for (uint32_t r = 0; r < R; ++r) {                    // prover.rs:198-225
+        uint32_t beta = c->info.beta_raw[r] = ch.get_u32();   // prover.rs:200
+        if ((rc = do_fold(c, r, beta))) return rc;        // prover.rs:201-211
+        if ((rc = do_merkle(c, 2 + r))) return rc;        // prover.rs:214
+        if ((rc = read_root(c, 2 + r, root))) return rc;
+        ch.commit_hash(root);                             // prover.rs:224
+        memcpy(c->info.roots[2 + r], root, 32);
+    }
+    // last layer: B evaluations of a degree-0 polynomial (prover.rs:238, :251); free term prover.rs:254
+    HIPCHK(hipMemcpyAsync(c->h_small, c->d_layers + c->layer_off[1 + R], B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 1; i < B; ++i)
+        if (c->h_small[i] != c->h_small[0])
+            return fail(ZK_ERR_CHECK, "last FRI layer is not constant (prover.rs:238): trace does not satisfy the constraints");
+    uint32_t free_term = c->info.free_term = c->h_small[0];
+    ch.commit_u32(free_term);                             // prover.rs:254
+    uint32_t qraw = c->info.query_raw = ch.get_u32();     // prover.rs:263
+    const size_t x = (size_t)qraw % (N - 2 * B);
+
+    // decommit (prover.rs:266-289): one gather for the values, one for the path digests
+    std::vector<uint64_t> voff, doff;
+    std::vector<size_t> nodes;
+    auto add_path = [&](uint32_t tree, size_t m, size_t leaf) {
+        nodes.clear();
+        path_nodes(m, leaf, nodes);
+        for (size_t nd : nodes) doff.push_back((uint64_t)c->tree_off[tree] + (uint64_t)nd * 8);
+    };
+    voff.push_back(c->layer_off[0] + x);         add_path(0, N, x);
+    voff.push_back(c->layer_off[0] + x + B);     add_path(0, N, x + B);
+    voff.push_back(c->layer_off[0] + x + 2 * B); add_path(0, N, x + 2 * B);
+    voff.push_back(c->layer_off[1] + x);         add_path(1, N, x);
+    for (uint32_t i = 0; i < R; ++i) {
+        size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
+        voff.push_back(c->layer_off[1 + i] + xi); add_path(1 + i, len, xi);
+        voff.push_back(c->layer_off[1 + i] + nx); add_path(1 + i, len, nx);
+    }
+    const size_t nv = voff.size(), ndg = doff.size();
+    if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
+    {
+        StageTimer tm(c, 4);
+        memcpy(c->h_gather_off, voff.data(), nv * 8);
+        memcpy(c->h_gather_off + nv, doff.data(), ndg * 8);
+        HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, (nv + ndg) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream));
+        HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint8_t> dig(ndg * 32);
+    for (size_t i = 0; i < ndg; ++i) digest_words_to_bytes(c->h_gather_out + nv + 8 * i, dig.data() + 32 * i);
+    const uint32_t* vals = c->h_gather_out;
+    const size_t Lp = c->L;
+    size_t dpos = 0;
+    for (int k = 0; k < 4; ++k) {                         // prover.rs:274-277
+        ch.commit_val_path(vals[k], dig.data() + 32 * dpos, Lp);
+        dpos += Lp;
+    }
+    for (uint32_t i = 0; i < R; ++i) {                    // prover.rs:280-289
+        size_t pl = Lp - i;
+        ch.commit_pair_paths(vals[4 + 2 * i], vals[5 + 2 * i], dig.data() + 32 * dpos, dig.data() + 32 * (dpos + pl), pl);
+        dpos += 2 * pl;
+    }
+    proof = std::move(ch.data);                           // channel.rs:34-36
+    memcpy(state_out, ch.state, 32);
+    if (c->profiling) collect_stage_times(c);
+    return ZK_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char* zk_last_error(void) { return g_last_error.c_str(); }
+const char* zk_version(void) { return "zkstark_amd 0.1 (gfx950)"; }
+
+uint32_t zk_field_add(uint32_t a, uint32_t b) { return add(a % P, b % P); }
+uint32_t zk_field_sub(uint32_t a, uint32_t b) { return sub(a % P, b % P); }
+uint32_t zk_field_mul(uint32_t a, uint32_t b) { return mulmod(a % P, b % P); }
+uint32_t zk_field_neg(uint32_t a) { return neg(a % P); }
+uint32_t zk_field_inv(uint32_t a) { return invmod(a % P); }
+uint32_t zk_field_pow(uint32_t a, uint32_t e) { return powmod(a, e); }
+uint32_t zk_field_from_u32(uint32_t v) { return v % P; }
+uint32_t zk_field_generator(void) { return GEN_W; }
+uint32_t zk_field_root_of_unity(uint32_t log_order) { return log_order > 30 ? 0 : root_of_unity(log_order); }
+
+int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
+    if (!out) return fail(ZK_ERR_INVALID, "zk_ctx_create: out is null");
+    *out = nullptr;
+    if (log_n < 2 || log_b < 1 || log_b > 5 || log_n + log_b > 30)
+        return fail(ZK_ERR_INVALID, "zk_ctx_create: need 2 <= log_n, 1 <= log_blowup <= 5, log_n + log_blowup <= 30 (got %u, %u)", log_n, log_b);
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(device));
+    zk_ctx* c = new (std::nothrow) zk_ctx();
+    if (!c) return fail(ZK_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->log_n = log_n; c->log_b = log_b; c->L = log_n + log_b;
+    c->n = (size_t)1 << log_n; c->B = (size_t)1 << log_b; c->N = c->n << log_b;
+    c->R = log_n;
+    c->plan = make_plan(log_n);
+    c->g = root_of_unity(log_n);
+    c->h = root_of_unity(c->L);
+    int rc = ZK_OK;
+    auto bail = [&](int code) { zk_ctx_destroy(c); return code; };
+#define HIPCHK_C(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            zk_ctx_destroy(c);                                                                \
+            return fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                     \
+    } while (0)
+    HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if ((rc = build_table(c->h, c->L, &c->H))) return bail(rc);
+    if ((rc = build_table(invmod(c->h), c->L, &c->Hinv))) return bail(rc);
+    if ((rc = build_table(GEN_W, log_n, &c->W))) return bail(rc);
+    uint32_t gm1 = invmod(c->g);
+    c->w_mont = to_mont(GEN_W);
+    c->gm1_mont = to_mont(gm1);
+    c->gm2_mont = to_mont(mulmod(gm1, gm1));
+    c->gm3_mont = to_mont(mulmod(mulmod(gm1, gm1), gm1));
+    c->ninv_mont = to_mont(invmod((uint32_t)(c->n % P)));
+    c->inv2_mont = to_mont(invmod(2));
+    // layers: 0 = f_eval (N), 1 + r = FRI layer r (N >> r), r = 0 .. R
+    size_t off = 0;
+    for (uint32_t l = 0; l <= c->R + 1; ++l) {
+        c->layer_off.push_back(off);
+        c->layer_len.push_back(layer_size(c, l));
+        off += layer_size(c, l);
+    }
+    size_t layer_words = off;
+    off = 0;
+    for (uint32_t l = 0; l <= c->R + 1; ++l) {
+        c->tree_off.push_back(off);
+        off += (2 * layer_size(c, l) - 1) * 8;
+    }
+    size_t tree_words = off;
+    if ((rc = dmalloc(c, &c->d_trace, c->n * 4))) return bail(rc);
+    if ((rc = dmalloc(c, &c->d_layers, layer_words * 4))) return bail(rc);
+    if ((rc = dmalloc(c, &c->d_trees, tree_words * 4))) return bail(rc);
+    if ((rc = dmalloc(c, &c->d_inv_xm1, c->N * 4))) return bail(rc);
+    c->gather_cap = (size_t)(4 + 2 * c->R) * (c->L + 1) + 64;
+    if ((rc = dmalloc(c, &c->d_gather_off, c->gather_cap * 8))) return bail(rc);
+    if ((rc = dmalloc(c, &c->d_gather_out, c->gather_cap * 32))) return bail(rc);
+    HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_gather_out, c->gather_cap * 32));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_small, 4096));
+    HIPCHK_C(launch_build_inv_xm1(c->d_inv_xm1, c->L, c->H.view(), c->stream));
+    HIPCHK_C(hipStreamSynchronize(c->stream));
+#undef HIPCHK_C
+    c->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = c;
+    return ZK_OK;
+}
+
+int zk_ctx_destroy(zk_ctx* c) {
+    if (!c) return ZK_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_table(&c->H); free_table(&c->Hinv); free_table(&c->W);
+    if (c->d_inv_xm1) (void)hipFree(c->d_inv_xm1);
+    if (c->d_trace) (void)hipFree(c->d_trace);
+    if (c->d_layers) (void)hipFree(c->d_layers);
+    if (c->d_trees) (void)hipFree(c->d_trees);
+    if (c->d_gather_off) (void)hipFree(c->d_gather_off);
+    if (c->d_gather_out) (void)hipFree(c->d_gather_out);
+    if (c->h_gather_off) (void)hipHostFree(c->h_gather_off);
+    if (c->h_gather_out) (void)hipHostFree(c->h_gather_out);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ZK_OK;
+}
+
+double zk_ctx_setup_ms(const zk_ctx* c) { return c ? c->setup_ms : 0.0; }
+size_t zk_ctx_device_bytes(const zk_ctx* c) { return c ? c->device_bytes : 0; }
+void* zk_ctx_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int zk_ctx_sync(zk_ctx* c) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+int zk_ctx_set_profiling(zk_ctx* c, int on) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    c->profiling = on != 0;
+    return ZK_OK;
+}
+
+int zk_trace_fibsq(uint32_t a0, uint32_t a1, size_t count, uint32_t* out) {
+    if (!out && count) return fail(ZK_ERR_INVALID, "zk_trace_fibsq: out is null");
+    if (count > 0) out[0] = a0 % P;                       // prover.rs:33
+    if (count > 1) out[1] = a1 % P;                       // prover.rs:34
+    for (size_t i = 2; i < count; ++i)                    // prover.rs:35-39
+        out[i] = add(mulmod(out[i - 2], out[i - 2]), mulmod(out[i - 1], out[i - 1]));
+    return ZK_OK;
+}
+
+int zk_trace_upload(zk_ctx* c, const uint32_t* trace, size_t count) {
+    if (!c || !trace) return fail(ZK_ERR_INVALID, "zk_trace_upload: null argument");
+    if (count != c->n - 1) return fail(ZK_ERR_INVALID, "zk_trace_upload: expected n-1 = %zu values, got %zu", c->n - 1, count);
+    for (size_t i = 0; i < count; ++i)
+        if (trace[i] >= P) return fail(ZK_ERR_INVALID, "zk_trace_upload: trace[%zu] = %u is not a canonical residue", i, trace[i]);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_trace, trace, count * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_trace + count, 0, 4, c->stream));   // slot n-1: see DESIGN.md "LDE"
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->first = trace[0];
+    c->last = trace[count - 1];                           // a[n-2], the public output (prover.rs:42)
+    c->have_trace = true;
+    c->have_lde = false;
+    return ZK_OK;
+}
+
+int zk_lde(zk_ctx* c) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_lde: no trace uploaded (the iNTT consumes it: upload again per proof)");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = do_lde(c);
+    c->have_trace = false;   // d_trace now holds coefficients
+    return rc;
+}
+
+int zk_merkle_commit(zk_ctx* c, uint32_t layer, uint8_t root_out[32]) {
+    if (!c || !root_out) return fail(ZK_ERR_INVALID, "zk_merkle_commit: null argument");
+    if (layer > c->R + 1) return fail(ZK_ERR_INVALID, "zk_merkle_commit: layer %u out of range", layer);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = do_merkle(c, layer);
+    if (rc) return rc;
+    return read_root(c, layer, root_out);
+}
+
+int zk_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
+    if (!c || !alpha_raw) return fail(ZK_ERR_INVALID, "zk_compose: null argument");
+    if (!c->have_lde) return fail(ZK_ERR_STATE, "zk_compose: run zk_lde first");
+    HIPCHK(hipSetDevice(c->device));
+    return do_compose(c, alpha_raw);
+}
+
+int zk_fri_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    if (round >= c->R) return fail(ZK_ERR_INVALID, "zk_fri_fold: round %u out of range (%u rounds)", round, c->R);
+    HIPCHK(hipSetDevice(c->device));
+    return do_fold(c, round, beta_raw);
+}
+
+int zk_layer_read(zk_ctx* c, uint32_t layer, size_t offset, size_t count, uint32_t* out) {
+    if (!c || (!out && count)) return fail(ZK_ERR_INVALID, "zk_layer_read: null argument");
+    if (layer > c->R + 1 || offset + count > layer_size(c, layer)) return fail(ZK_ERR_INVALID, "zk_layer_read: out of range");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->d_layers + c->layer_off[layer] + offset, count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_layer_write(zk_ctx* c, uint32_t layer, size_t offset, size_t count, const uint32_t* in) {
+    if (!c || (!in && count)) return fail(ZK_ERR_INVALID, "zk_layer_write: null argument");
+    if (layer > c->R + 1 || offset + count > layer_size(c, layer)) return fail(ZK_ERR_INVALID, "zk_layer_write: out of range");
+    for (size_t i = 0; i < count; ++i)
+        if (in[i] >= P) return fail(ZK_ERR_INVALID, "zk_layer_write: value %zu is not a canonical residue", i);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_layers + c->layer_off[layer] + offset, in, count * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (layer == 0) c->have_lde = true;
+    return ZK_OK;
+}
+
+int zk_merkle_node(zk_ctx* c, uint32_t tree, size_t index, uint8_t out[32]) {
+    if (!c || !out) return fail(ZK_ERR_INVALID, "zk_merkle_node: null argument");
+    if (tree > c->R + 1 || index >= 2 * layer_size(c, tree) - 1) return fail(ZK_ERR_INVALID, "zk_merkle_node: out of range");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->h_small, c->d_trees + c->tree_off[tree] + index * 8, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    digest_words_to_bytes(c->h_small, out);
+    return ZK_OK;
+}
+
+int zk_merkle_path(zk_ctx* c, uint32_t tree, size_t leaf, uint8_t* out, size_t* path_len) {
+    if (!c || !out) return fail(ZK_ERR_INVALID, "zk_merkle_path: null argument");
+    if (tree > c->R + 1 || leaf >= layer_size(c, tree)) return fail(ZK_ERR_INVALID, "zk_merkle_path: out of range");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<size_t> nodes;
+    path_nodes(layer_size(c, tree), leaf, nodes);
+    for (size_t i = 0; i < nodes.size(); ++i) c->h_gather_off[i] = (uint64_t)c->tree_off[tree] + (uint64_t)nodes[i] * 8;
+    HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, nodes.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_gather(c->d_trees, c->d_gather_off, (uint32_t)nodes.size(), 8, c->d_gather_out, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, nodes.size() * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < nodes.size(); ++i) digest_words_to_bytes(c->h_gather_out + 8 * i, out + 32 * i);
+    if (path_len) *path_len = nodes.size();
+    return ZK_OK;
+}
+
+int zk_prove_resident(zk_ctx* c, uint8_t* proof_out, size_t cap, size_t* proof_len, uint8_t state_out[32]) {
+    if (!c || !proof_out || !state_out) return fail(ZK_ERR_INVALID, "zk_prove_resident: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<uint8_t> proof;
+    uint8_t st[32];
+    int rc = prove_resident(c, proof, st);
+    c->have_trace = false;
+    if (rc) return rc;
+    if (proof_len) *proof_len = proof.size();
+    if (proof.size() > cap) return fail(ZK_ERR_BUFFER, "zk_prove: proof needs %zu bytes, buffer has %zu", proof.size(), cap);
+    memcpy(proof_out, proof.data(), proof.size());
+    memcpy(state_out, st, 32);
+    return ZK_OK;
+}
+
+int zk_prove(zk_ctx* c, const uint32_t* trace, size_t count, uint8_t* proof_out, size_t cap, size_t* proof_len,
+             uint8_t state_out[32]) {
+    int rc = zk_trace_upload(c, trace, count);
+    if (rc) return rc;
+    return zk_prove_resident(c, proof_out, cap, proof_len, state_out);
+}
+
+int zk_last_transcript(const zk_ctx* c, zk_transcript_info* out) {
+    if (!c || !out) return fail(ZK_ERR_INVALID, "zk_last_transcript: null argument");
+    *out = c->info;
+    return ZK_OK;
+}
+
+int zk_last_stage_ms(const zk_ctx* c, double out[5]) {
+    if (!c || !out) return fail(ZK_ERR_INVALID, "zk_last_stage_ms: null argument");
+    for (int i = 0; i < 5; ++i) out[i] = c->stage_ms[i];
+    return ZK_OK;
+}
+
+int zk_verify(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last) {
+    if (!proof) return fail(ZK_ERR_INVALID, "zk_verify: null proof");
+    int rc = verify_proof(proof, len, log_n, log_b, public_last);
+    if (rc) return fail(ZK_ERR_VERIFY, "proof rejected at check %d (proof.rs:15-149)", rc);
+    return ZK_OK;
+}
+
+size_t zk_proof_size(size_t data_len) { return 48 + data_len; }   // proof.rs:151-154: size_of::<Proof>() = 32 + 16
+size_t zk_proof_data_len(uint32_t log_n, uint32_t log_b) { return proof_data_len(log_n, log_b); }
+
+int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t* path, size_t path_len, uint8_t out[32]) {
+    if ((!path && path_len) || !out || path_len > 62) return fail(ZK_ERR_INVALID, "zk_compute_root_from_path: bad argument");
+    compute_root_from_path(element, index, path, path_len, out);
+    return ZK_OK;
+}
+
+// ---- Channel -------------------------------------------------------------------
+struct zk_channel {
+    Channel ch;
+};
+int zk_channel_new(zk_channel** out) {
+    if (!out) return fail(ZK_ERR_INVALID, "null argument");
+    *out = new (std::nothrow) zk_channel();
+    return *out ? ZK_OK : fail(ZK_ERR_NOMEM, "out of host memory");
+}
+int zk_channel_free(zk_channel* ch) { delete ch; return ZK_OK; }
+int zk_channel_commit(zk_channel* ch, const uint8_t* bytes, size_t n) {
+    if (!ch || (!bytes && n)) return fail(ZK_ERR_INVALID, "null argument");
+    ch->ch.commit_bytes(bytes, n);
+    return ZK_OK;
+}
+int zk_channel_get_u32(zk_channel* ch, uint32_t* out) {
+    if (!ch || !out) return fail(ZK_ERR_INVALID, "null argument");
+    *out = ch->ch.get_u32();
+    return ZK_OK;
+}
+int zk_channel_state(const zk_channel* ch, uint8_t out[32]) {
+    if (!ch || !out) return fail(ZK_ERR_INVALID, "null argument");
+    memcpy(out, ch->ch.state, 32);
+    return ZK_OK;
+}
+size_t zk_channel_data_len(const zk_channel* ch) { return ch ? ch->ch.data.size() : 0; }
+int zk_channel_data(const zk_channel* ch, uint8_t* out, size_t cap) {
+    if (!ch || !out) return fail(ZK_ERR_INVALID, "null argument");
+    if (ch->ch.data.size() > cap) return fail(ZK_ERR_BUFFER, "buffer too small");
+    memcpy(out, ch->ch.data.data(), ch->ch.data.size());
+    return ZK_OK;
+}
+
+// ---- stand-alone primitives --------------------------------------------------------
+int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
+    if (!d_vals || !d_nodes || log_m > 30) return fail(ZK_ERR_INVALID, "zk_dev_merkle_build: bad argument");
+    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream));
+    return ZK_OK;
+}
+
+int zk_dev_merkle_node(const uint32_t* d_nodes, size_t index, uint8_t out[32], void* stream) {
+    if (!d_nodes || !out) return fail(ZK_ERR_INVALID, "zk_dev_merkle_node: null argument");
+    uint32_t w[8];
+    HIPCHK(hipMemcpyAsync(w, d_nodes + index * 8, 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    digest_words_to_bytes(w, out);
+    return ZK_OK;
+}
+
+int zk_merkle_build_host(int device, const uint32_t* vals, size_t m, uint8_t* nodes_out) {
+    if (!vals || !nodes_out) return fail(ZK_ERR_INVALID, "zk_merkle_build_host: null argument");
+    if (m == 0 || (m & (m - 1)) || m > ((size_t)1 << 30))      // merkle.rs:16-21 asserts a power of two
+        return fail(ZK_ERR_INVALID, "zk_merkle_build_host: size %zu is not a power of two (merkle.rs:18)", m);
+    uint32_t log_m = 0;
+    while (((size_t)1 << log_m) < m) ++log_m;
+    HIPCHK(hipSetDevice(device));
+    uint32_t *d_vals = nullptr, *d_nodes = nullptr;
+    size_t words = (2 * m - 1) * 8;
+    HIPCHK(hipMalloc(&d_vals, m * 4));
+    hipError_t e = hipMalloc(&d_nodes, words * 4);
+    if (e != hipSuccess) { (void)hipFree(d_vals); return fail(ZK_ERR_NOMEM, "hipMalloc failed"); }
+    int rc = ZK_OK;
+    std::vector<uint32_t> host(words);
+    do {
+        if (hipMemcpy(d_vals, vals, m * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "H2D failed"); break; }
+        if (launch_merkle_build(d_vals, log_m, d_nodes, nullptr) != hipSuccess) { rc = fail(ZK_ERR_HIP, "merkle launch failed"); break; }
+        if (hipMemcpy(host.data(), d_nodes, words * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "D2H failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    } while (0);
+    (void)hipFree(d_vals); (void)hipFree(d_nodes);
+    if (rc) return rc;
+    for (size_t i = 0; i < 2 * m - 1; ++i) digest_words_to_bytes(host.data() + 8 * i, nodes_out + 32 * i);
+    return ZK_OK;
+}
+
+int zk_ntt_host(int device, uint32_t* data, uint32_t log_m, int inverse) {
+    if (!data || log_m < 1 || log_m > 30) return fail(ZK_ERR_INVALID, "zk_ntt_host: bad argument");
+    size_t m = (size_t)1 << log_m;
+    for (size_t i = 0; i < m; ++i)
+        if (data[i] >= P) return fail(ZK_ERR_INVALID, "zk_ntt_host: data[%zu] is not a canonical residue", i);
+    HIPCHK(hipSetDevice(device));
+    uint32_t root = root_of_unity(log_m);
+    DevTable T;
+    int rc = build_table(inverse ? invmod(root) : root, log_m, &T);
+    if (rc) return rc;
+    Plan pl = make_plan(log_m);
+    uint32_t *d_a = nullptr, *d_b = nullptr;
+    HIPCHK(hipMalloc(&d_a, m * 4));
+    HIPCHK(hipMalloc(&d_b, m * 4));
+    do {
+        if (hipMemcpy(d_a, data, m * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "H2D failed"); break; }
+        uint32_t* res = d_a;
+        if (inverse) {
+            if ((rc = run_dif(d_a, log_m, pl, T.view(), log_m, to_mont(invmod((uint32_t)(m % P))), nullptr))) break;
+            if (launch_digit_reverse(d_a, d_b, log_m, pl.nd, pl.bits, 1, nullptr) != hipSuccess) { rc = fail(ZK_ERR_HIP, "launch failed"); break; }
+            res = d_b;
+        } else {
+            if (launch_digit_reverse(d_a, d_b, log_m, pl.nd, pl.bits, 0, nullptr) != hipSuccess) { rc = fail(ZK_ERR_HIP, "launch failed"); break; }
+            if ((rc = run_dit(d_b, log_m, pl, T.view(), log_m, nullptr))) break;
+            res = d_b;
+        }
+        if (hipMemcpy(data, res, m * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "D2H failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    } while (0);
+    (void)hipFree(d_a); (void)hipFree(d_b);
+    free_table(&T);
+    return rc;
+}
+
+int zk_lde_host(int device, const uint32_t* trace, uint32_t log_n, uint32_t log_b, uint32_t* out) {
+    if (!trace || !out) return fail(ZK_ERR_INVALID, "zk_lde_host: null argument");
+    zk_ctx* c = nullptr;
+    int rc = zk_ctx_create(device, log_n, log_b, &c);
+    if (rc) return rc;
+    rc = zk_trace_upload(c, trace, c->n - 1);
+    if (!rc) rc = zk_lde(c);
+    if (!rc) rc = zk_layer_read(c, 0, 0, c->N, out);
+    zk_ctx_destroy(c);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference interface, written over the C ABI (ctypes).
+
+Names, argument meaning and error behaviour follow the reference so that tests
+read like the reference's own (the reference panics; here a ZkError is raised).
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _lib
+from ._lib import ZkError, check
+
+P = 3221225473  # main.rs:13
+
+
+def _u32arr(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class field:
+    """Scalar Gf<P> arithmetic (field.rs:8-211) on canonical residues."""
+    P = P
+
+    @staticmethod
+    def add(a, b): return _lib.load().zk_field_add(a, b)
+    @staticmethod
+    def sub(a, b): return _lib.load().zk_field_sub(a, b)
+    @staticmethod
+    def mul(a, b): return _lib.load().zk_field_mul(a, b)
+    @staticmethod
+    def neg(a): return _lib.load().zk_field_neg(a)
+    @staticmethod
+    def inv(a): return _lib.load().zk_field_inv(a)
+    @staticmethod
+    def pow(a, e): return _lib.load().zk_field_pow(a, e)
+    @staticmethod
+    def from_u32(v): return _lib.load().zk_field_from_u32(v)
+    @staticmethod
+    def generator(): return _lib.load().zk_field_generator()
+    @staticmethod
+    def root_of_unity(log_order): return _lib.load().zk_field_root_of_unity(log_order)
+
+
+def trace_fibsq(count, a0=1, a1=3141592):
+    """prover.rs:32-39."""
+    out = np.zeros(count, dtype=np.uint32)
+    check(_lib.load().zk_trace_fibsq(a0, a1, count, _ptr(out)))
+    return out
+
+
+# ---- bincode 1.x default encoding of the types the prover commits ----
+def encode(x):
+    if isinstance(x, (bytes, bytearray)):          # Hash = [u8; 32]: raw
+        return bytes(x)
+    if isinstance(x, (int, np.integer)):           # u32
+        return struct.pack("<I", int(x))
+    if isinstance(x, list):                        # AuthPath = Box<[Hash]>
+        return struct.pack("<Q", len(x)) + b"".join(bytes(h) for h in x)
+    if isinstance(x, tuple):
+        return b"".join(encode(e) for e in x)
+    raise TypeError(f"cannot encode {type(x)}")
+
+
+class Channel:
+    """channel.rs:6-37."""
+
+    def __init__(self):                              # channel.rs:12
+        self._h = C.c_void_p()
+        check(_lib.load().zk_channel_new(C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().zk_channel_free(self._h)
+            self._h = None
+
+    def commit(self, data):                          # channel.rs:19
+        b = encode(data)
+        check(_lib.load().zk_channel_commit(self._h, b, len(b)))
+
+    def get_u32(self):                               # channel.rs:28
+        v = C.c_uint32()
+        check(_lib.load().zk_channel_get_u32(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def state(self):
+        out = C.create_string_buffer(32)
+        check(_lib.load().zk_channel_state(self._h, out))
+        return out.raw
+
+    @property
+    def data(self):
+        n = _lib.load().zk_channel_data_len(self._h)
+        out = C.create_string_buffer(max(n, 1))
+        check(_lib.load().zk_channel_data(self._h, out, n))
+        return out.raw[:n]
+
+    def finalize(self, log_n=10, log_blowup=3, public_last=2338775057):   # channel.rs:34
+        return Proof(self.state, self.data, log_n, log_blowup, public_last)
+
+
+class Proof:
+    """proof.rs:5-154.  verify() raises ZkError where the reference panics."""
+
+    def __init__(self, state, data, log_n=10, log_blowup=3, public_last=2338775057):   # proof.rs:11
+        self.state, self.data = bytes(state), bytes(data)
+        self.log_n, self.log_blowup, self.public_last = log_n, log_blowup, public_last
+
+    def verify(self):                                # proof.rs:15
+        check(_lib.load().zk_verify(self.data, len(self.data), self.log_n, self.log_blowup, self.public_last))
+
+    def size(self):                                  # proof.rs:151
+        return _lib.load().zk_proof_size(len(self.data))
+
+
+def compute_root_from_path(element, index, path):
+    """merkle.rs:82-110."""
+    flat = b"".join(bytes(h) for h in path)
+    out = C.create_string_buffer(32)
+    check(_lib.load().zk_compute_root_from_path(element, index, flat, len(path), out))
+    return out.raw
+
+
+class Merkle:
+    """merkle.rs:6-79: SHA-256 heap built on the GPU; merkle[i], merkle.trace(i)."""
+
+    def __init__(self, size, data, device=0):        # Merkle::new, merkle.rs:14
+        vals = _u32arr(list(data) if not isinstance(data, np.ndarray) else data)
+        if len(vals) != size:
+            raise ZkError(-1, f"Merkle.new: size {size} != len(data) {len(vals)}")
+        self.size = size
+        self.nodes = np.zeros((max(2 * size - 1, 1), 32), dtype=np.uint8)
+        check(_lib.load().zk_merkle_build_host(device, _ptr(vals), size, _ptr(self.nodes)))
+
+    new = classmethod(lambda cls, size, data, device=0: cls(size, data, device))
+
+    def __getitem__(self, i):                        # merkle.rs:74-79
+        return bytes(self.nodes[i])
+
+    def __len__(self):
+        return len(self.nodes)
+
+    def trace(self, i):                              # merkle.rs:54-71
+        i += len(self.nodes) // 2
+        v = []
+        while i != 0:
+            if i % 2 == 0:
+                v.append(self[i - 1]); i -= 2
+            else:
+                v.append(self[i + 1]); i -= 1
+            i >>= 1
+        return v
+
+
+def ntt(data, inverse=False, device=0):
+    """Natural-order NTT of size 2^k with root field.root_of_unity(k)."""
+    a = _u32arr(data).copy()
+    k = int(len(a)).bit_length() - 1
+    if len(a) != 1 << k:
+        raise ZkError(-1, "ntt: length must be a power of two")
+    check(_lib.load().zk_ntt_host(device, _ptr(a), k, 1 if inverse else 0))
+    return a
+
+
+def lde(trace, log_n, log_blowup, device=0):
+    """lagrange + solve over the coset (prover.rs:60-70) as one call."""
+    t = _u32arr(trace)
+    out = np.zeros(1 << (log_n + log_blowup), dtype=np.uint32)
+    check(_lib.load().zk_lde_host(device, _ptr(t), log_n, log_blowup, _ptr(out)))
+    return out
+
+
+class Context:
+    """Device-resident prover state for one (log_n, log_blowup): zk_ctx."""
+
+    def __init__(self, log_n=10, log_blowup=3, device=0):
+        self.log_n, self.log_blowup, self.device = log_n, log_blowup, device
+        self.n, self.B = 1 << log_n, 1 << log_blowup
+        self.N, self.rounds = self.n * self.B, log_n
+        self._h = C.c_void_p()
+        check(_lib.load().zk_ctx_create(device, log_n, log_blowup, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().zk_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    @property
+    def setup_ms(self): return _lib.load().zk_ctx_setup_ms(self._h)
+    @property
+    def device_bytes(self): return _lib.load().zk_ctx_device_bytes(self._h)
+    @property
+    def stream(self): return _lib.load().zk_ctx_stream(self._h)
+
+    def sync(self): check(_lib.load().zk_ctx_sync(self._h))
+    def set_profiling(self, on): check(_lib.load().zk_ctx_set_profiling(self._h, int(on)))
+
+    def layer_size(self, layer): return self.N if layer == 0 else self.N >> (layer - 1)
+
+    def trace_upload(self, trace):
+        t = _u32arr(trace)
+        check(_lib.load().zk_trace_upload(self._h, _ptr(t), len(t)))
+
+    def lde(self): check(_lib.load().zk_lde(self._h))
+
+    def merkle_commit(self, layer):
+        out = C.create_string_buffer(32)
+        check(_lib.load().zk_merkle_commit(self._h, layer, out))
+        return out.raw
+
+    def compose(self, alpha_raw):
+        a = _u32arr(alpha_raw)
+        check(_lib.load().zk_compose(self._h, _ptr(a)))
+
+    def fri_fold(self, rnd, beta_raw): check(_lib.load().zk_fri_fold(self._h, rnd, beta_raw))
+
+    def layer_read(self, layer, offset=0, count=None):
+        if count is None:
+            count = self.layer_size(layer) - offset
+        out = np.zeros(count, dtype=np.uint32)
+        check(_lib.load().zk_layer_read(self._h, layer, offset, count, _ptr(out)))
+        return out
+
+    def layer_write(self, layer, values, offset=0):
+        v = _u32arr(values)
+        check(_lib.load().zk_layer_write(self._h, layer, offset, len(v), _ptr(v)))
+
+    def merkle_node(self, tree, index):
+        out = C.create_string_buffer(32)
+        check(_lib.load().zk_merkle_node(self._h, tree, index, out))
+        return out.raw
+
+    def merkle_path(self, tree, leaf):
+        buf = C.create_string_buffer(32 * 64)
+        n = C.c_size_t()
+        check(_lib.load().zk_merkle_path(self._h, tree, leaf, buf, C.byref(n)))
+        return [buf.raw[32 * i:32 * i + 32] for i in range(n.value)]
+
+    def prove(self, trace=None):
+        """generate_proof as one C call (C++ host prover). trace=None: already uploaded."""
+        cap = _lib.load().zk_proof_data_len(self.log_n, self.log_blowup)
+        buf = C.create_string_buffer(cap)
+        st = C.create_string_buffer(32)
+        n = C.c_size_t()
+        if trace is None:
+            check(_lib.load().zk_prove_resident(self._h, buf, cap, C.byref(n), st))
+        else:
+            t = _u32arr(trace)
+            check(_lib.load().zk_prove(self._h, _ptr(t), len(t), buf, cap, C.byref(n), st))
+        info = self.last_transcript()
+        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, info.public_last)
+
+    def last_transcript(self):
+        info = _lib.TranscriptInfo()
+        check(_lib.load().zk_last_transcript(self._h, C.byref(info)))
+        return info
+
+    def last_stage_ms(self):
+        out = (C.c_double * 5)()
+        check(_lib.load().zk_last_stage_ms(self._h, C.byref(out)))
+        return dict(zip(("lde", "merkle", "compose", "fri_fold", "decommit"), list(out)))
+
+
+def generate_proof(channel, log_n=10, log_blowup=3, a0=1, a1=3141592, ctx=None):
+    """prover.rs:9-293, stage by stage over the C ABI, driven by `channel`.
+
+    The reference literals are the defaults (trace 1023 values, domain 8192).
+    Context.prove() is the same flow inside one C call.
+    """
+    own = ctx is None
+    ctx = ctx or Context(log_n, log_blowup)
+    try:
+        n, B, N, R = ctx.n, ctx.B, ctx.N, ctx.rounds
+        a = trace_fibsq(n - 1, a0, a1)                       # prover.rs:32-39
+        ctx.trace_upload(a)
+        ctx.lde()                                            # prover.rs:60-70
+        channel.commit(ctx.merkle_commit(0))                 # prover.rs:81-85
+        alphas = [channel.get_u32() for _ in range(3)]       # prover.rs:163-165
+        ctx.compose(alphas)                                  # prover.rs:166-173
+        channel.commit(ctx.merkle_commit(1))                 # prover.rs:176-180
+        for r in range(R):                                   # prover.rs:198-225
+            beta = channel.get_u32()
+            ctx.fri_fold(r, beta)
+            channel.commit(ctx.merkle_commit(2 + r))
+        last = ctx.layer_read(1 + R)
+        if not (last == last[0]).all():                      # prover.rs:238
+            raise ZkError(-7, "last FRI layer is not constant")
+        channel.commit(int(last[0]))                         # prover.rs:254
+        x = channel.get_u32() % (N - 2 * B)                  # prover.rs:263
+        for layer, idx in ((0, x), (0, x + B), (0, x + 2 * B), (1, x)):      # prover.rs:266-277
+            channel.commit((int(ctx.layer_read(layer, idx, 1)[0]), ctx.merkle_path(layer, idx)))
+        for i in range(R):                                   # prover.rs:280-289
+            ln = N >> i
+            xi = x % ln
+            nx = (xi + ln // 2) % ln
+            channel.commit((int(ctx.layer_read(1 + i, xi, 1)[0]), int(ctx.layer_read(1 + i, nx, 1)[0]),
+                            ctx.merkle_path(1 + i, xi), ctx.merkle_path(1 + i, nx)))
+        return channel.finalize(log_n, log_blowup, int(a[n - 2]))   # prover.rs:292
+    finally:
+        if own:
+            ctx.close()
