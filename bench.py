@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- STARK-101 prover throughput on MI355X.
+
+Metric (BASELINE.json): field-elements/s through LDE + Merkle + FRI = N / t, N = evaluation
+domain size, t = wall time from "trace values resident on the device" to "proof bytes on the
+host" (context / twiddle setup excluded, reported separately).  Default workload: the full
+prover at domain 2^24 (BASELINE.json configs[2]; trace group 2^21, blow-up 8) on synthetic
+Fibonacci-square traces.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 21] [--log-blowup 3]
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel
+(merkle_subtree_kernel<leaf>), timed live with HIP events on the context stream inside the
+timed region; `cpu_baseline` is the CPU oracle (oracle/, a port of the reference algorithm
+with O(N log N) transforms) on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=21, help="log2 of the trace group size n")
+    ap.add_argument("--log-blowup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=17, help="oracle sample: domain 2^(this+blowup)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_log_n, log_b):
+    """Times the CPU oracle (kind 'port': the reference is a Rust crate that cannot be built
+    here) on a bounded sample of the same workload: the full prover at a smaller domain."""
+    import oracle
+    cores = min(os.cpu_count() or 1, 16)
+    N = 1 << (sample_log_n + log_b)
+    oracle.set_threads(cores)
+    oracle.prove(sample_log_n - 3, log_b, want_vectors=False)        # page in, spin up threads
+    t0 = time.perf_counter()
+    r = oracle.prove(sample_log_n, log_b, want_vectors=False)
+    dt_all = time.perf_counter() - t0
+    assert r.rc == 0
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    oracle.prove(sample_log_n - 1, log_b, want_vectors=False)
+    dt_one = time.perf_counter() - t0
+    return {
+        "value": N / dt_all, "unit": "field-elements/s", "cores": cores, "kind": "port",
+        "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads, {dt_all:.2f} s",
+        "single_thread_value": (N // 2) / dt_one,
+        "single_thread_sample": f"domain 2^{sample_log_n + log_b - 1}, 1 thread, {dt_one:.2f} s",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import zkstark_amd as zk
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log_n, log_b = args.log_n, args.log_blowup
+    N = 1 << (log_n + log_b)
+
+    if world > 1:
+        from zkstark_amd import sharded
+        result = sharded.bench(args, rank, local_rank, world, barrier)
+    else:
+        ctx = zk.Context(log_n, log_b, device=local_rank)
+        trace = zk.trace_fibsq((1 << log_n) - 1)
+        ctx.trace_upload(trace)                      # resident before the timed region
+        for _ in range(args.warmup):
+            proof = ctx.prove()
+        ctx.set_profiling(("merkle_leaf",))          # events around the dominant kernel only
+        ctx.kernel_stats(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            proof = ctx.prove()
+        barrier()
+        dt = time.perf_counter() - t0
+        dom = ctx.kernel_stats(reset=True)["merkle_leaf"]
+        proof.verify()
+        # one extra untimed step with every kernel class bracketed: per-stage table
+        ctx.set_profiling("all")
+        ctx.prove()
+        per_kernel = ctx.kernel_stats(reset=True)
+        ctx.set_profiling(())
+        result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": ctx.setup_ms,
+                  "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
+                  "units": N * args.steps, "parallelism": "single-gpu"}
+        ctx.close()
+
+    dt = result["dt"]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = result["units"] / dt
+        dom = result["dom"]
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
+        traffic = None
+        if os.path.exists(PROFILE_TRAFFIC):
+            with open(PROFILE_TRAFFIC) as f:
+                traffic = json.load(f).get("merkle_leaf_bytes_per_launch")
+        # SHA-256 work of the dominant kernel in 32-bit lane-ops (1 leaf + inner hashes)
+        roofline = {
+            "kernel": "merkle_subtree_kernel<leaf>", "bound": "hbm",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+            "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+            "note": "SHA-256 is integer-VALU bound, not HBM bound (SURVEY.md 8d); see stages[] for the HBM-bound kernels",
+        }
+        stages = []
+        for name, st in result["per_kernel"].items():
+            if st["launches"]:
+                gbs = st["bytes"] / (st["ms"] * 1e-3) / 1e9 if st["ms"] > 0 else 0.0
+                stages.append({"kernel": name, "launches": st["launches"], "ms": round(st["ms"], 4),
+                               "algorithmic_GB": round(st["bytes"] / 1e9, 4), "GBps": round(gbs, 1),
+                               "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+        out = {
+            "metric": "field-elements/s through LDE+Merkle+FRI (full STARK-101 prover)",
+            "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": result["scaling"], "vs_baseline": None, "dtype": "u32 (mod 3*2^30+1) + SHA-256",
+            "data": "synthetic Fibonacci-square trace (a0=1, a1=3141592), deterministic",
+            "config": {"workload": f"full prover: LDE + compose + FRI + Merkle, domain 2^{log_n + log_b} "
+                                   f"(trace group 2^{log_n}, blow-up {1 << log_b})" + (f" per proof; {result['parallelism']}" if world > 1 else ""),
+                       "log_n": log_n, "log_blowup": log_b, "domain": N, "fri_rounds": log_n,
+                       "parallelism": result["parallelism"]},
+            "roofline": roofline,
+            "stages": stages,
+            "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],
+            "proof_bytes": result["proof_bytes"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,11 +120,27 @@ typedef struct zk_transcript_info {
     uint8_t roots[34][32]; /* trees 0 .. log_n + 1 */
 } zk_transcript_info;
 int zk_last_transcript(const zk_ctx *ctx, zk_transcript_info *out);
-/* Per-stage device time of the last zk_prove* in milliseconds (HIP events on the ctx
- * stream): [0] lde, [1] merkle, [2] compose, [3] fri fold, [4] decommit gather. */
-int zk_last_stage_ms(const zk_ctx *ctx, double out[5]);
-/* Per-stage event timing is off by default (it adds event records to the stream). */
-int zk_ctx_set_profiling(zk_ctx *ctx, int on);
+/* Optional per-kernel timing with HIP events on the context stream.  class_mask selects
+ * the kernel classes to bracket (bit i = class i below; 0 = off, the default), so a
+ * benchmark can time only the dominant kernel inside its timed region. */
+enum zk_kernel_class {
+    ZK_K_NTT = 0,           /* ntt_pass_kernel (iNTT / LDE passes) */
+    ZK_K_MERKLE_LEAF = 1,   /* merkle_subtree_kernel<leaf>: leaf hashes + k inner levels */
+    ZK_K_MERKLE_INNER = 2,  /* merkle_subtree_kernel<inner> */
+    ZK_K_MERKLE_TOP = 3,    /* merkle_top_kernel */
+    ZK_K_COMPOSE = 4,
+    ZK_K_FOLD = 5,
+    ZK_K_GATHER = 6,
+    ZK_K_COUNT = 7
+};
+typedef struct zk_kernel_stat {
+    uint64_t launches;
+    double ms;     /* summed launch durations */
+    double bytes;  /* summed ALGORITHMIC bytes of those launches */
+} zk_kernel_stat;
+int zk_ctx_set_profiling(zk_ctx *ctx, uint32_t class_mask);
+/* Copies the accumulated statistics (count <= ZK_K_COUNT entries); reset != 0 clears them. */
+int zk_kernel_stats(zk_ctx *ctx, zk_kernel_stat *out, size_t count, int reset);
 
 /* ---- proof: proof.rs ------------------------------------------------------- */
 /* Proof::verify (proof.rs:15-149), CPU only, generalised from the literals

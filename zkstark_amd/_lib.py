@@ -27,6 +27,13 @@ class TranscriptInfo(C.Structure):
                 ("query_raw", C.c_uint32), ("public_last", C.c_uint32), ("roots", (C.c_uint8 * 32) * 34)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double)]
+
+
+KERNEL_CLASSES = ("ntt", "merkle_leaf", "merkle_inner", "merkle_top", "compose", "fri_fold", "gather")
+
+
 # name -> (restype, argtypes); every symbol include/zkstark_amd.h declares
 _u32, _sz, _vp, _int, _dbl = C.c_uint32, C.c_size_t, C.c_void_p, C.c_int, C.c_double
 _cp = C.c_char_p
@@ -48,7 +55,8 @@ SYMBOLS = {
     "zk_ctx_device_bytes": (_sz, [_vp]),
     "zk_ctx_sync": (_int, [_vp]),
     "zk_ctx_stream": (_vp, [_vp]),
-    "zk_ctx_set_profiling": (_int, [_vp, _int]),
+    "zk_ctx_set_profiling": (_int, [_vp, _u32]),
+    "zk_kernel_stats": (_int, [_vp, _vp, _sz, _int]),
     "zk_trace_fibsq": (_int, [_u32, _u32, _sz, _vp]),
     "zk_trace_upload": (_int, [_vp, _vp, _sz]),
     "zk_lde": (_int, [_vp]),
@@ -62,7 +70,6 @@ SYMBOLS = {
     "zk_prove_resident": (_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_prove": (_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
-    "zk_last_stage_ms": (_int, [_vp, C.POINTER(_dbl * 5)]),
     "zk_verify": (_int, [_vp, _sz, _u32, _u32, _u32]),
     "zk_proof_size": (_sz, [_sz]),
     "zk_proof_data_len": (_sz, [_u32, _u32]),

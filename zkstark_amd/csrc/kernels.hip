@@ -170,7 +170,11 @@ __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(NttPassArgs p) {
     }
 }
 
-hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s) {
+hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Profiler* prof) {
+    // algorithmic bytes: every element read once and written once (the LDE pass reads n, writes N)
+    double bytes = mode == NTT_DIT_LDE ? 4.0 * ((double)(1u << a.log_n) + (double)((size_t)1 << a.log_total))
+                                       : 8.0 * (double)((size_t)1 << a.log_total);
+    ScopedKernelTimer tm(prof, K_NTT, bytes, s);
     uint32_t cols_log = a.log_total - a.logR;
     uint32_t blocks = 1u << (cols_log - a.logC);
     size_t shmem = ((size_t)(1u << a.logR) * ((1u << a.logC) + 1u) + (1u << a.logR) / 2u) * sizeof(uint32_t);
@@ -278,8 +282,9 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
     a.cp[i] = add(add(t0, t1), t2);
 }
 
-hipError_t launch_compose(const ComposeArgs& a, hipStream_t s) {
+hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof) {
     size_t N = (size_t)1 << a.logN;
+    ScopedKernelTimer tm(prof, K_COMPOSE, 8.0 * (double)N, s);   // read f once, write cp once
     uint32_t blocks = (uint32_t)((N + 255) / 256);
     hipLaunchKernelGGL(compose_kernel, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -301,8 +306,9 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a) {
     a.out[i] = add(s, d);
 }
 
-hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s) {
+hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
     size_t half = (size_t)1 << (a.log_m - 1);
+    ScopedKernelTimer tm(prof, K_FOLD, 12.0 * (double)half, s);   // read m words, write m/2
     uint32_t blocks = (uint32_t)((half + 255) / 256);
     hipLaunchKernelGGL(fri_fold_kernel, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -422,10 +428,19 @@ __global__ __launch_bounds__(kTopThreads) void merkle_top_kernel(const uint32_t*
     }
 }
 
-hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s) {
+// Algorithmic bytes of a launch that takes 2^depth inputs down k levels: inputs read once
+// (4 B values or 32 B digests), every produced digest written once.
+static double merkle_bytes(bool leaf, uint32_t depth, uint32_t k) {
+    double in = (double)((size_t)1 << depth);
+    double produced = (leaf ? in : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k));
+    return (leaf ? 4.0 : 32.0) * in + 32.0 * produced;
+}
+
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof) {
     uint32_t depth = log_m;
     if (depth <= kMerkleTopLog) {
         size_t sh = ((size_t)2 << depth) * sizeof(uint4);
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(true, depth, depth), s);
         hipLaunchKernelGGL(merkle_top_kernel<true>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
         return hipGetLastError();
     }
@@ -438,12 +453,14 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         size_t lanes = (size_t)1 << (depth - k);
         uint32_t blocks = (uint32_t)((lanes + kMerkleThreads - 1) / kMerkleThreads);
         size_t sh = (size_t)k * 2 * kMerkleThreads * sizeof(uint4);
+        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s);
         if (leaf) hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
         else hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
         leaf = false;
         depth -= k;
     }
     size_t sh = ((size_t)2 << depth) * sizeof(uint4);
+    ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(false, depth, depth), s);
     hipLaunchKernelGGL(merkle_top_kernel<false>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
     return hipGetLastError();
 }
@@ -459,8 +476,9 @@ __global__ void gather_kernel(const uint32_t* src, const uint64_t* offsets, uint
 }
 
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
-                         uint32_t* out, hipStream_t s) {
+                         uint32_t* out, hipStream_t s, Profiler* prof) {
     if (!count) return hipSuccess;
+    ScopedKernelTimer tm(prof, K_GATHER, 8.0 * (double)count * words, s);
     uint32_t total = count * words, blocks = (total + 255) / 256;
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, src, offsets, count, words, out);
     return hipGetLastError();

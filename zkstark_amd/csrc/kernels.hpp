@@ -5,7 +5,48 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace zk {
+
+// ---- optional per-kernel timing (HIP events on the launch stream) ---------------
+// Kernel classes; a context times only the classes whose bit is set in Profiler::mask,
+// so a benchmark can bracket just the dominant kernel inside its timed region.
+enum KernelClass : int {
+    K_NTT = 0,
+    K_MERKLE_LEAF = 1,    // merkle_subtree_kernel<true>: leaf hashes + k inner levels
+    K_MERKLE_INNER = 2,   // merkle_subtree_kernel<false>
+    K_MERKLE_TOP = 3,     // merkle_top_kernel
+    K_COMPOSE = 4,
+    K_FOLD = 5,
+    K_GATHER = 6,
+    K_COUNT = 7
+};
+
+struct Profiler {
+    uint32_t mask = 0;
+    struct Rec { int cls; hipEvent_t a, b; double bytes; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    bool on(int cls) const { return (mask >> cls) & 1u; }
+};
+
+// Brackets one kernel launch; bytes = algorithmic bytes of that launch.
+struct ScopedKernelTimer {
+    Profiler* p; int cls; double bytes; hipStream_t s; hipEvent_t a = nullptr;
+    ScopedKernelTimer(Profiler* p_, int cls_, double bytes_, hipStream_t s_) : p(p_), cls(cls_), bytes(bytes_), s(s_) {
+        if (p && p->on(cls)) { a = p->get(); (void)hipEventRecord(a, s); }
+    }
+    ~ScopedKernelTimer() {
+        if (a) { hipEvent_t b = p->get(); (void)hipEventRecord(b, s); p->recs.push_back({cls, a, b, bytes}); }
+    }
+};
 
 // Two-level table of powers of a fixed root, entries in Montgomery form:
 //   root^e = hi[e >> lo_bits] * lo[e & ((1 << lo_bits) - 1)]
@@ -43,7 +84,7 @@ struct NttPassArgs {
     uint32_t dig_bits[kMaxDigits];
 };
 
-hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s);
+hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Profiler* prof = nullptr);
 // out[pos] = in[true_index(pos)] for the mixed-radix digit reversal (standalone NTT API only)
 hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_m, uint32_t nd,
                                 const uint32_t* dig_bits, int to_natural, hipStream_t s);
@@ -65,7 +106,7 @@ struct ComposeArgs {
     uint32_t alpha1g2_mont;   // alpha1 * g^2
     uint32_t zz[32];          // B entries: alpha2 / (x^n - 1) * R^2  (per i mod B)
 };
-hipError_t launch_compose(const ComposeArgs& a, hipStream_t s);
+hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof = nullptr);
 
 struct FoldArgs {
     const uint32_t* in;   // m values
@@ -77,14 +118,14 @@ struct FoldArgs {
     uint32_t inv2_mont;   // 1/2
     uint32_t c_mont;      // beta * w^(-2^r) / 2
 };
-hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
+hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof = nullptr);
 
 // Merkle tree over m = 2^log_m u32 leaves.  nodes: (2m-1) * 8 words, heap order
 // (merkle.rs:14-51), each node the eight SHA-256 state words.
-hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s);
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr);
 
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
-                         uint32_t* out, hipStream_t s);
+                         uint32_t* out, hipStream_t s, Profiler* prof = nullptr);
 
 }  // namespace zk

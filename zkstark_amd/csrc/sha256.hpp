@@ -47,8 +47,24 @@ ZK_SHA_HD uint32_t sha_rotr(uint32_t x, int n) {
 constexpr uint32_t SHA_IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
                                 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
 
+// Three-input boolean functions.  gfx950 has v_bitop3_b32 (any 3-input truth table in one
+// VALU op; the table is the function evaluated on a=0xF0, b=0xCC, c=0xAA); hipcc does not form
+// it for the rotate-xor sums on its own, which costs ~20 % more instructions per compression.
+// Compile-time-constant operands stay on plain operators so that they still fold.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_BITOP3(a, b, c, tt, expr) \
+    ((__builtin_constant_p(a) && __builtin_constant_p(b) && __builtin_constant_p(c)) ? (expr) : __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt)))
+#else
+#define ZK_BITOP3(a, b, c, tt, expr) (expr)
+#endif
+ZK_SHA_HD uint32_t sha_xor3(uint32_t a, uint32_t b, uint32_t c) { return ZK_BITOP3(a, b, c, 0x96, a ^ b ^ c); }
+ZK_SHA_HD uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return ZK_BITOP3(e, f, g, 0xCA, (e & f) | (~e & g)); }
+ZK_SHA_HD uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return ZK_BITOP3(a, b, c, 0xE8, (a & b) | (a & c) | (b & c)); }
+
 // One compression, fully unrolled with a rolling 16-word schedule.  Every call
 // site is inlined, so constant message words / constant chaining values fold away.
+// Per round: 6 v_alignbit + 2 xor3 + ch + maj + 4 adds (add3 where possible) = 14 VALU ops;
+// per schedule step: 4 v_alignbit/shift + 2 xor3 + 2 adds = 10.
 ZK_SHA_HD void sha256_compress(uint32_t st[8], uint32_t w[16]) {
     uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
@@ -58,18 +74,16 @@ ZK_SHA_HD void sha256_compress(uint32_t st[8], uint32_t w[16]) {
             wi = w[i];
         } else {
             uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
-            uint32_t s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
-            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            uint32_t s0 = sha_xor3(sha_rotr(w15, 7), sha_rotr(w15, 18), w15 >> 3);
+            uint32_t s1 = sha_xor3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
+            wi = (w[i & 15] + s0 + w[(i - 7) & 15]) + s1;
             w[i & 15] = wi;
         }
-        uint32_t S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
-        uint32_t ch = (e & f) ^ (~e & g);
-        uint32_t t1 = h + S1 + ch + SHA_K[i] + wi;
-        uint32_t S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
-        uint32_t mj = ((a ^ b) & c) | (~(a ^ b) & b);   // == maj(a,b,c), one v_bfi_b32
-        uint32_t t2 = S0 + mj;
-        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        uint32_t S1 = sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25));
+        uint32_t t1 = (h + S1 + sha_ch(e, f, g)) + (SHA_K[i] + wi);
+        uint32_t S0 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22));
+        uint32_t mj = sha_maj(a, b, c);
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
     }
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }

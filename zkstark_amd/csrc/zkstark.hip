@@ -99,15 +99,15 @@ void free_table(DevTable* t) {
 }
 
 // Inverse transform, natural order in, digit-reversed out, optionally scaled by scale_mont.
-int run_dif(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw_inv, uint32_t L, uint32_t scale_mont, hipStream_t s) {
+int run_dif(const uint32_t* src, uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw_inv, uint32_t L, uint32_t scale_mont, hipStream_t s, Profiler* prof = nullptr) {
     uint32_t inner = log_m;
     for (uint32_t d = 0; d < pl.nd; ++d) {
         inner -= pl.bits[d];
         NttPassArgs a{};
-        a.src = data; a.dst = data; a.log_total = log_m;
+        a.src = d == 0 ? src : data; a.dst = data; a.log_total = log_m;
         a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR);
         a.L = L; a.tw = tw_inv; a.scale_mont = (inner == 0) ? scale_mont : 0;
-        HIPCHK(launch_ntt_pass(a, NTT_DIF, s));
+        HIPCHK(launch_ntt_pass(a, NTT_DIF, s, prof));
     }
     return ZK_OK;
 }
@@ -139,7 +139,8 @@ struct zk_ctx {
     DevTable H, Hinv, W;
     uint32_t* d_inv_xm1 = nullptr;
     Plan plan;
-    uint32_t* d_trace = nullptr;    // n words: trace, then coefficients (digit-reversed order)
+    uint32_t* d_trace = nullptr;    // n words: a[0..n-2], 0   (stays resident across proofs)
+    uint32_t* d_coef = nullptr;     // n words: interpolant coefficients, digit-reversed order
     uint32_t* d_layers = nullptr;   // layer 0 (N) | layer 1 (N) | layer 2 (N/2) | ... | layer R+1 (B)
     std::vector<size_t> layer_off, layer_len;
     uint32_t* d_trees = nullptr;    // tree t over layer t, (2m-1)*8 words each
@@ -159,10 +160,8 @@ struct zk_ctx {
     bool have_trace = false, have_lde = false;
     uint32_t first = 0, last = 0;
     zk_transcript_info info{};
-    bool profiling = false;
-    double stage_ms[5] = {0, 0, 0, 0, 0};
-    std::vector<hipEvent_t> ev;
-    std::vector<int> ev_stage;
+    Profiler prof;
+    zk_kernel_stat kstat[K_COUNT] = {};
 };
 
 namespace {
@@ -178,38 +177,26 @@ int dmalloc(zk_ctx* c, T** p, size_t bytes) {
 size_t layer_size(const zk_ctx* c, uint32_t layer) { return layer == 0 ? c->N : (c->N >> (layer - 1)); }
 uint32_t layer_log(const zk_ctx* c, uint32_t layer) { return layer == 0 ? c->L : c->L - (layer - 1); }
 
-struct StageTimer {
-    zk_ctx* c;
-    int stage;
-    hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(zk_ctx* c_, int st) : c(c_), stage(st) {
-        if (!c->profiling) return;
-        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, c->stream);
-    }
-    ~StageTimer() {
-        if (!c->profiling) return;
-        (void)hipEventRecord(b, c->stream);
-        c->ev.push_back(a); c->ev.push_back(b); c->ev_stage.push_back(stage);
-    }
-};
+Profiler* prof_of(zk_ctx* c) { return c->prof.mask ? &c->prof : nullptr; }
 
-void collect_stage_times(zk_ctx* c) {
-    for (int i = 0; i < 5; ++i) c->stage_ms[i] = 0;
-    for (size_t i = 0; i < c->ev_stage.size(); ++i) {
+// Resolves pending event pairs into the per-class accumulators (synchronises on them).
+void collect_kernel_stats(zk_ctx* c) {
+    for (auto& r : c->prof.recs) {
         float ms = 0;
-        (void)hipEventSynchronize(c->ev[2 * i + 1]);
-        (void)hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]);
-        c->stage_ms[c->ev_stage[i]] += ms;
-        (void)hipEventDestroy(c->ev[2 * i]); (void)hipEventDestroy(c->ev[2 * i + 1]);
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        c->kstat[r.cls].launches += 1;
+        c->kstat[r.cls].ms += ms;
+        c->kstat[r.cls].bytes += r.bytes;
+        c->prof.pool.push_back(r.a);
+        c->prof.pool.push_back(r.b);
     }
-    c->ev.clear(); c->ev_stage.clear();
+    c->prof.recs.clear();
 }
 
 int do_lde(zk_ctx* c) {
-    StageTimer tm(c, 0);
     // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
-    int rc = run_dif(c->d_trace, c->log_n, c->plan, c->Hinv.view(), c->L, 0, c->stream);
+    int rc = run_dif(c->d_trace, c->d_coef, c->log_n, c->plan, c->Hinv.view(), c->L, 0, c->stream, prof_of(c));
     if (rc) return rc;
     // size-N forward transform of the zero-padded, w^k-scaled coefficients
     uint32_t* f = c->d_layers + c->layer_off[0];
@@ -221,14 +208,14 @@ int do_lde(zk_ctx* c) {
         a.dst = f;
         if (d == (int)c->plan.nd - 1) {
             if (a.logC < c->log_b) a.logC = c->log_b;
-            a.src = c->d_trace;
+            a.src = c->d_coef;
             a.wtab = c->W.view(); a.log_n = c->log_n; a.ninv_mont = c->ninv_mont;
             a.nd = c->plan.nd;
             for (uint32_t q = 0; q < c->plan.nd; ++q) a.dig_bits[q] = c->plan.bits[q];
-            HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, c->stream));
+            HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, c->stream, prof_of(c)));
         } else {
             a.src = f;
-            HIPCHK(launch_ntt_pass(a, NTT_DIT, c->stream));
+            HIPCHK(launch_ntt_pass(a, NTT_DIT, c->stream, prof_of(c)));
         }
         inner += c->plan.bits[d];
     }
@@ -237,14 +224,12 @@ int do_lde(zk_ctx* c) {
 }
 
 int do_merkle(zk_ctx* c, uint32_t layer) {
-    StageTimer tm(c, 1);
     HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer),
-                               c->d_trees + c->tree_off[layer], c->stream));
+                               c->d_trees + c->tree_off[layer], c->stream, prof_of(c)));
     return ZK_OK;
 }
 
 int do_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
-    StageTimer tm(c, 2);
     ComposeArgs a{};
     a.f = c->d_layers + c->layer_off[0];
     a.inv_xm1 = c->d_inv_xm1;
@@ -263,12 +248,11 @@ int do_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
         a.zz[r] = to_mont(to_mont(mulmod(a2, zinv)));
         xn = mulmod(xn, hn);
     }
-    HIPCHK(launch_compose(a, c->stream));
+    HIPCHK(launch_compose(a, c->stream, prof_of(c)));
     return ZK_OK;
 }
 
 int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
-    StageTimer tm(c, 3);
     FoldArgs a{};
     a.in = c->d_layers + c->layer_off[1 + round];
     a.out = c->d_layers + c->layer_off[2 + round];
@@ -279,7 +263,7 @@ int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
     a.inv2_mont = c->inv2_mont;
     uint32_t winv = invmod(powmod(GEN_W, (uint64_t)1 << round));
     a.c_mont = to_mont(mulmod(mulmod(beta_raw % P, winv), invmod(2)));
-    HIPCHK(launch_fri_fold(a, c->stream));
+    HIPCHK(launch_fri_fold(a, c->stream, prof_of(c)));
     return ZK_OK;
 }
 
@@ -360,12 +344,11 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     const size_t nv = voff.size(), ndg = doff.size();
     if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
     {
-        StageTimer tm(c, 4);
         memcpy(c->h_gather_off, voff.data(), nv * 8);
         memcpy(c->h_gather_off + nv, doff.data(), ndg * 8);
         HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, (nv + ndg) * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream));
-        HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream));
+        HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream, prof_of(c)));
+        HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream, prof_of(c)));
         HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -385,7 +368,6 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     }
     proof = std::move(ch.data);                           // channel.rs:34-36
     memcpy(state_out, ch.state, 32);
-    if (c->profiling) collect_stage_times(c);
     return ZK_OK;
 }
 
@@ -461,6 +443,7 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     }
     size_t tree_words = off;
     if ((rc = dmalloc(c, &c->d_trace, c->n * 4))) return bail(rc);
+    if ((rc = dmalloc(c, &c->d_coef, c->n * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_layers, layer_words * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_trees, tree_words * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_inv_xm1, c->N * 4))) return bail(rc);
@@ -485,6 +468,7 @@ int zk_ctx_destroy(zk_ctx* c) {
     free_table(&c->H); free_table(&c->Hinv); free_table(&c->W);
     if (c->d_inv_xm1) (void)hipFree(c->d_inv_xm1);
     if (c->d_trace) (void)hipFree(c->d_trace);
+    if (c->d_coef) (void)hipFree(c->d_coef);
     if (c->d_layers) (void)hipFree(c->d_layers);
     if (c->d_trees) (void)hipFree(c->d_trees);
     if (c->d_gather_off) (void)hipFree(c->d_gather_off);
@@ -492,6 +476,8 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (c->h_gather_off) (void)hipHostFree(c->h_gather_off);
     if (c->h_gather_out) (void)hipHostFree(c->h_gather_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    collect_kernel_stats(c);
+    for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ZK_OK;
@@ -505,9 +491,17 @@ int zk_ctx_sync(zk_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
-int zk_ctx_set_profiling(zk_ctx* c, int on) {
+int zk_ctx_set_profiling(zk_ctx* c, uint32_t class_mask) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
-    c->profiling = on != 0;
+    c->prof.mask = class_mask & ((1u << K_COUNT) - 1u);
+    return ZK_OK;
+}
+
+int zk_kernel_stats(zk_ctx* c, zk_kernel_stat* out, size_t count, int reset) {
+    if (!c || (!out && count)) return fail(ZK_ERR_INVALID, "zk_kernel_stats: null argument");
+    collect_kernel_stats(c);
+    for (size_t i = 0; i < count && i < (size_t)K_COUNT; ++i) out[i] = c->kstat[i];
+    if (reset) for (int i = 0; i < K_COUNT; ++i) c->kstat[i] = zk_kernel_stat{};
     return ZK_OK;
 }
 
@@ -538,11 +532,9 @@ int zk_trace_upload(zk_ctx* c, const uint32_t* trace, size_t count) {
 
 int zk_lde(zk_ctx* c) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
-    if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_lde: no trace uploaded (the iNTT consumes it: upload again per proof)");
+    if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_lde: no trace uploaded");
     HIPCHK(hipSetDevice(c->device));
-    int rc = do_lde(c);
-    c->have_trace = false;   // d_trace now holds coefficients
-    return rc;
+    return do_lde(c);
 }
 
 int zk_merkle_commit(zk_ctx* c, uint32_t layer, uint8_t root_out[32]) {
@@ -621,7 +613,6 @@ int zk_prove_resident(zk_ctx* c, uint8_t* proof_out, size_t cap, size_t* proof_l
     std::vector<uint8_t> proof;
     uint8_t st[32];
     int rc = prove_resident(c, proof, st);
-    c->have_trace = false;
     if (rc) return rc;
     if (proof_len) *proof_len = proof.size();
     if (proof.size() > cap) return fail(ZK_ERR_BUFFER, "zk_prove: proof needs %zu bytes, buffer has %zu", proof.size(), cap);
@@ -640,12 +631,6 @@ int zk_prove(zk_ctx* c, const uint32_t* trace, size_t count, uint8_t* proof_out,
 int zk_last_transcript(const zk_ctx* c, zk_transcript_info* out) {
     if (!c || !out) return fail(ZK_ERR_INVALID, "zk_last_transcript: null argument");
     *out = c->info;
-    return ZK_OK;
-}
-
-int zk_last_stage_ms(const zk_ctx* c, double out[5]) {
-    if (!c || !out) return fail(ZK_ERR_INVALID, "zk_last_stage_ms: null argument");
-    for (int i = 0; i < 5; ++i) out[i] = c->stage_ms[i];
     return ZK_OK;
 }
 
@@ -757,7 +742,7 @@ int zk_ntt_host(int device, uint32_t* data, uint32_t log_m, int inverse) {
         if (hipMemcpy(d_a, data, m * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "H2D failed"); break; }
         uint32_t* res = d_a;
         if (inverse) {
-            if ((rc = run_dif(d_a, log_m, pl, T.view(), log_m, to_mont(invmod((uint32_t)(m % P))), nullptr))) break;
+            if ((rc = run_dif(d_a, d_a, log_m, pl, T.view(), log_m, to_mont(invmod((uint32_t)(m % P))), nullptr))) break;
             if (launch_digit_reverse(d_a, d_b, log_m, pl.nd, pl.bits, 1, nullptr) != hipSuccess) { rc = fail(ZK_ERR_HIP, "launch failed"); break; }
             res = d_b;
         } else {

@@ -203,7 +203,20 @@ class Context:
     def stream(self): return _lib.load().zk_ctx_stream(self._h)
 
     def sync(self): check(_lib.load().zk_ctx_sync(self._h))
-    def set_profiling(self, on): check(_lib.load().zk_ctx_set_profiling(self._h, int(on)))
+    def set_profiling(self, classes=()):
+        """Time the named kernel classes (_lib.KERNEL_CLASSES) with HIP events; () = off, "all" = every class."""
+        if classes == "all":
+            classes = _lib.KERNEL_CLASSES
+        mask = 0
+        for c in classes:
+            mask |= 1 << _lib.KERNEL_CLASSES.index(c)
+        check(_lib.load().zk_ctx_set_profiling(self._h, mask))
+
+    def kernel_stats(self, reset=True):
+        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
+        check(_lib.load().zk_kernel_stats(self._h, arr, len(arr), int(reset)))
+        return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes}
+                for name, a in zip(_lib.KERNEL_CLASSES, arr)}
 
     def layer_size(self, layer): return self.N if layer == 0 else self.N >> (layer - 1)
 
@@ -264,11 +277,6 @@ class Context:
         info = _lib.TranscriptInfo()
         check(_lib.load().zk_last_transcript(self._h, C.byref(info)))
         return info
-
-    def last_stage_ms(self):
-        out = (C.c_double * 5)()
-        check(_lib.load().zk_last_stage_ms(self._h, C.byref(out)))
-        return dict(zip(("lde", "merkle", "compose", "fri_fold", "decommit"), list(out)))
 
 
 def generate_proof(channel, log_n=10, log_blowup=3, a0=1, a1=3141592, ctx=None):
