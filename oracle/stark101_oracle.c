@@ -894,6 +894,9 @@ int orc_prove(uint32_t log_n, uint32_t log_b, uint32_t a0, uint32_t a1, int mode
               orc_debug *dbg) {
     if (log_n < 2 || log_b < 1 || log_n + log_b > 30) return -100;
     if (mode == ORC_MODE_NAIVE && log_n > 10) return -101;
+    /* n = 8 is degenerate: g^4 = -1 makes the leading terms of f(gx)^2 + f(x)^2 cancel, so c2 has
+     * degree < n-1 and the generalised asserts of prover.rs:156 / :169 fail (the reference would panic). */
+    if (log_n == 3) return -103;
     orc_channel ch; orc_channel_new(&ch);                       /* main.rs:19 */
     int rc = mode == ORC_MODE_NAIVE ? prove_naive(log_n, log_b, a0, a1, &ch, dbg)
                                     : prove_ntt(log_n, log_b, a0, a1, &ch, dbg);

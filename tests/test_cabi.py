@@ -1,0 +1,135 @@
+"""The C-ABI library loads, exports every symbol include/zkstark_amd.h declares, and its host-only
+entry points (field, channel, verifier, wire format) agree with the oracle.  No GPU, no compute calls."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import struct
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+P = 3221225473
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "zkstark_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(zk):
+    from zkstark_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/zkstark_amd.h but not exported"
+    assert set(_lib.SYMBOLS) == set(syms), set(_lib.SYMBOLS) ^ set(syms)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must not import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "zkstark_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libzkstark_amd.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_field_matches_oracle(zk, orc):
+    f = zk.field
+    assert f.generator() == 5 == orc.generator()
+    assert f.root_of_unity(10) == orc.gen_of_order_log(10) == f.pow(5, 3145728)     # prover.rs:48
+    assert f.root_of_unity(13) == f.pow(5, 393216)                                   # prover.rs:49
+    import random
+    rnd = random.Random(1)
+    for _ in range(2000):
+        a, b = rnd.randrange(P), rnd.randrange(P)
+        assert f.add(a, b) == orc.add(a, b) == (a + b) % P
+        assert f.sub(a, b) == orc.sub(a, b) == (a - b) % P
+        assert f.mul(a, b) == orc.mul(a, b) == a * b % P
+        assert f.neg(a) == (-a) % P
+    for a in (1, 2, 5, P - 1, 123456789):
+        assert f.mul(a, f.inv(a)) == 1
+    assert f.from_u32(3235878091) == 3235878091 - P        # field.rs:20-24: reduce raw u32 >= P
+    assert f.add(P - 1, P - 1) == P - 2                    # P > 2^31: a + b overflows u32
+
+
+def test_trace_fibsq(zk, orc):
+    a = zk.trace_fibsq(1023)
+    assert a[1022] == 2338775057                            # prover.rs:42
+    assert (a == orc.trace_fibsq(1023)).all()
+
+
+def test_channel_matches_hashlib(zk):
+    """channel.rs:11-37 with the bincode encodings of SURVEY Appendix B."""
+    ch = zk.Channel()
+    assert ch.state == bytes(32) and ch.data == b""
+    root = bytes(range(32))
+    ch.commit(root)
+    st = hashlib.sha256(bytes(32) + root).digest()
+    assert ch.state == st
+    v = ch.get_u32()
+    assert v == struct.unpack(">I", st[:4])[0]              # channel.rs:29 big-endian
+    st = hashlib.sha256(st + struct.pack("<I", v)).digest()  # committed little-endian (bincode)
+    assert ch.state == st
+    path = [bytes([i]) * 32 for i in range(3)]
+    ch.commit((7, path))
+    enc = struct.pack("<I", 7) + struct.pack("<Q", 3) + b"".join(path)
+    st = hashlib.sha256(st + enc).digest()
+    assert ch.state == st
+    assert ch.data == root + struct.pack("<I", v) + enc
+
+
+def test_verifier_and_wire_format(zk, orc):
+    canon = json.load(open(os.path.join(GOLD, "stark101_canonical.json")))["derived"]
+    proof = zk.Proof(bytes.fromhex(canon["final_state"]), bytes.fromhex(canon["proof_hex"]))
+    proof.verify()                                           # proof.rs:15
+    assert proof.size() == 7884                              # proof.rs:151-154
+    from zkstark_amd import _lib
+    assert _lib.load().zk_proof_data_len(10, 3) == 7836
+    for pos in (3, 33, 80, 500, 7000):
+        bad = bytearray(proof.data)
+        bad[pos] ^= 0x80
+        with pytest.raises(zk.ZkError):
+            zk.Proof(proof.state, bytes(bad)).verify()
+    with pytest.raises(zk.ZkError):
+        zk.Proof(proof.state, proof.data, public_last=1).verify()
+    for row in json.load(open(os.path.join(GOLD, "prover_sizes.json"))):
+        if row["log_n"] > 8:
+            continue
+        r = orc.prove(row["log_n"], row["log_blowup"], 1, row["a1"], want_vectors=False)
+        zk.Proof(r.state, r.proof, row["log_n"], row["log_blowup"], row["public_last"]).verify()
+
+
+def test_compute_root_from_path_host(zk, orc):
+    nodes = orc.merkle_build([1, 2, 3, 4])
+    path = orc.merkle_trace(nodes, 0)
+    assert zk.compute_root_from_path(1, 0, [bytes(p) for p in path]) == bytes(nodes[0])   # merkle.rs:181
+
+
+def test_compute_calls_fail_loudly_without_gpu(zk):
+    """No CPU fallback: without a visible GPU every compute entry point raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(zk.ZkError):
+        zk.Context(10, 3)
+    with pytest.raises(zk.ZkError):
+        zk.Merkle.new(4, [1, 2, 3, 4])
+    with pytest.raises(zk.ZkError):
+        zk.ntt([1, 2, 3, 4])
+
+
+def test_context_argument_checks(zk):
+    for log_n, log_b in ((1, 3), (10, 0), (10, 6), (28, 3), (3, 3)):
+        with pytest.raises(zk.ZkError) as e:
+            zk.Context(log_n, log_b)
+        assert e.value.code == -1

@@ -78,7 +78,7 @@ def test_lde_reference_checkpoints(zk):
     assert list(f[-3:]) == [800520420, 1199720174, 1076821037]
 
 
-@pytest.mark.parametrize("log_n,log_b", [(2, 1), (3, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1)])
+@pytest.mark.parametrize("log_n,log_b", [(2, 1), (4, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1)])
 def test_lde_matches_oracle(zk, orc, log_n, log_b):
     rng = np.random.default_rng(300 + log_n * 8 + log_b)
     trace = rand_field(rng, (1 << log_n) - 1)   # arbitrary trace values, not only Fibonacci-square
@@ -139,7 +139,7 @@ def test_generate_proof_staged_equals_one_call(zk):
     p1.verify()
 
 
-@pytest.mark.parametrize("log_n,log_b,a1", [(2, 1, 3141592), (3, 3, 7), (6, 2, 3141592), (12, 3, 99), (15, 3, 3141592), (17, 3, 5)])
+@pytest.mark.parametrize("log_n,log_b,a1", [(2, 1, 3141592), (4, 3, 7), (6, 2, 3141592), (12, 3, 99), (15, 3, 3141592), (17, 3, 5)])
 def test_prover_other_sizes(zk, orc, log_n, log_b, a1):
     want = orc.prove(log_n, log_b, 1, a1, want_vectors=False)
     assert want.rc == 0

@@ -396,6 +396,8 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     *out = nullptr;
     if (log_n < 2 || log_b < 1 || log_b > 5 || log_n + log_b > 30)
         return fail(ZK_ERR_INVALID, "zk_ctx_create: need 2 <= log_n, 1 <= log_blowup <= 5, log_n + log_blowup <= 30 (got %u, %u)", log_n, log_b);
+    if (log_n == 3)   // g^4 = -1: the leading terms of f(gx)^2 + f(x)^2 cancel and deg c2 < n-1
+        return fail(ZK_ERR_INVALID, "zk_ctx_create: n = 8 is degenerate for the Fibonacci-square constraints (the degree asserts of prover.rs:156/:169 would fail)");
     auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(device));
     zk_ctx* c = new (std::nothrow) zk_ctx();
