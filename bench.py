@@ -25,7 +25,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+# 32-bit VALU: 64 lanes/clk/CU measured for every op SHA-256 uses (tools/valu_microbench.hip):
+# 256 CUs x 64 lanes x 2.4 GHz = 39.3 T lane-ops/s nominal; 35 T measured at the clock the chip holds.
+VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
 
 
@@ -37,7 +39,7 @@ def parse():
     ap.add_argument("--log-n", type=int, default=21, help="log2 of the trace group size n")
     ap.add_argument("--log-blowup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=17, help="oracle sample: domain 2^(this+blowup)")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=20, help="oracle sample: domain 2^(this+blowup)")
     return ap.parse_args()
 
 
@@ -55,13 +57,13 @@ def cpu_baseline(sample_log_n, log_b):
     assert r.rc == 0
     oracle.set_threads(1)
     t0 = time.perf_counter()
-    oracle.prove(sample_log_n - 1, log_b, want_vectors=False)
+    oracle.prove(sample_log_n - 3, log_b, want_vectors=False)
     dt_one = time.perf_counter() - t0
     return {
         "value": N / dt_all, "unit": "field-elements/s", "cores": cores, "kind": "port",
         "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads, {dt_all:.2f} s",
-        "single_thread_value": (N // 2) / dt_one,
-        "single_thread_sample": f"domain 2^{sample_log_n + log_b - 1}, 1 thread, {dt_one:.2f} s",
+        "single_thread_value": (N // 8) / dt_one,
+        "single_thread_sample": f"domain 2^{sample_log_n + log_b - 3}, 1 thread, {dt_one:.2f} s",
     }
 
 
@@ -79,10 +81,18 @@ def main():
     import torch.distributed as dist
     import zkstark_amd as zk
 
+    # ZK_BENCH_STAGED=1 rehearses the N > 1 path on a one-GPU box: every rank uses cuda:0 and the
+    # collectives go through gloo (host-staged).  Never a measurement configuration.
+    staged = os.environ.get("ZK_BENCH_STAGED") == "1"
+    if staged:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -94,7 +104,9 @@ def main():
 
     if world > 1:
         from zkstark_amd import sharded
-        result = sharded.bench(args, rank, local_rank, world, barrier)
+        result = sharded.bench(args, rank, local_rank, world, barrier, staged=staged)
+        log_n = result["log_n"]
+        N = 1 << (log_n + log_b)
     else:
         ctx = zk.Context(log_n, log_b, device=local_rank)
         trace = zk.trace_fibsq((1 << log_n) - 1)
@@ -123,7 +135,7 @@ def main():
 
     dt = result["dt"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -143,7 +155,11 @@ def main():
             "traffic": traffic,
             "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
             "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
-            "note": "SHA-256 is integer-VALU bound, not HBM bound (SURVEY.md 8d); see stages[] for the HBM-bound kernels",
+            "note": "SHA-256 is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu{}; stages[] lists the HBM-bound kernels",
+            "valu": {"achieved": dom["ops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0, "peak": VALU_PEAK_TOPS,
+                     "unit": "T lane-ops/s (32-bit)",
+                     "frac": (dom["ops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS) if dom["ms"] > 0 else 0.0,
+                     "ops_per_leaf_hash": 1259, "ops_per_inner_hash": 2293},
         }
         stages = []
         for name, st in result["per_kernel"].items():
@@ -151,7 +167,8 @@ def main():
                 gbs = st["bytes"] / (st["ms"] * 1e-3) / 1e9 if st["ms"] > 0 else 0.0
                 stages.append({"kernel": name, "launches": st["launches"], "ms": round(st["ms"], 4),
                                "algorithmic_GB": round(st["bytes"] / 1e9, 4), "GBps": round(gbs, 1),
-                               "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+                               "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "valu_frac": round(st["ops"] / (st["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4) if st["ms"] > 0 and st["ops"] else None})
         out = {
             "metric": "field-elements/s through LDE+Merkle+FRI (full STARK-101 prover)",
             "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps,

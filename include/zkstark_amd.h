@@ -137,6 +137,7 @@ typedef struct zk_kernel_stat {
     uint64_t launches;
     double ms;     /* summed launch durations */
     double bytes;  /* summed ALGORITHMIC bytes of those launches */
+    double ops;    /* summed compulsory 32-bit VALU lane-ops (SHA-256 kernels; 0 elsewhere) */
 } zk_kernel_stat;
 int zk_ctx_set_profiling(zk_ctx *ctx, uint32_t class_mask);
 /* Copies the accumulated statistics (count <= ZK_K_COUNT entries); reset != 0 clears them. */
@@ -164,6 +165,11 @@ int zk_channel_state(const zk_channel *ch, uint8_t out[32]);
 size_t zk_channel_data_len(const zk_channel *ch);
 int zk_channel_data(const zk_channel *ch, uint8_t *out, size_t cap);         /* channel.rs:34 */
 
+/* Timing of the zk_dev_* launches (process-wide; same classes and semantics as
+ * zk_ctx_set_profiling / zk_kernel_stats). */
+int zk_dev_set_profiling(uint32_t class_mask);
+int zk_dev_kernel_stats(zk_kernel_stat *out, size_t count, int reset);
+
 /* ---- stand-alone primitives on host buffers (upload, run on the GPU, download) -- */
 /* Merkle::new(size, data) (merkle.rs:14): nodes_out = (2m-1)*32 bytes, heap order. */
 int zk_merkle_build_host(int device, const uint32_t *vals, size_t m, uint8_t *nodes_out);
@@ -173,7 +179,29 @@ int zk_ntt_host(int device, uint32_t *data, uint32_t log_m, int inverse);
 /* trace (n-1 values) -> N coset evaluations (same as zk_trace_upload + zk_lde + read). */
 int zk_lde_host(int device, const uint32_t *trace, uint32_t log_n, uint32_t log_blowup, uint32_t *out);
 
-/* ---- device-pointer primitives (stream-ordered; for external orchestration) ---- */
+/* ---- coset domains and device-pointer primitives (stream-ordered) ------------------
+ * For callers that own the device buffers and the orchestration (the multi-GPU prover in
+ * zkstark_amd/sharded.py drives these between RCCL collectives).  A domain is
+ * {shift * h^i, i < 2^(log_n+log_blowup)}, h = zk_field_root_of_unity(log_n+log_blowup), with
+ * the tables the kernels need; the reference's domain is shift = 5 (prover.rs:69).  log_blowup
+ * may be 0.  fold_only != 0 builds only what zk_dev_fri_fold needs. */
+typedef struct zk_dom zk_dom;
+int zk_dom_create(int device, uint32_t log_n, uint32_t log_blowup, uint32_t shift, int fold_only, zk_dom **out);
+int zk_dom_destroy(zk_dom *dom);
+/* lagrange + solve (polynomial.rs:337, :49; prover.rs:60-70).  d_trace: n words = a[0..n-2] followed
+ * by 0; d_coef: n words scratch; d_out: N words, natural order. */
+int zk_dev_lde(const zk_dom *dom, const uint32_t *d_trace, uint32_t *d_coef, uint32_t *d_out, void *stream);
+/* prover.rs:101-173 pointwise; first = a[0], last = a[n-2]. */
+int zk_dev_compose(const zk_dom *dom, const uint32_t *d_f, uint32_t *d_cp, uint32_t first, uint32_t last,
+                   const uint32_t alpha_raw[3], void *stream);
+/* polynomial.rs:385 + prover.rs:204-211: 2^log_m values of FRI layer `round` -> 2^(log_m-1). */
+int zk_dev_fri_fold(const zk_dom *dom, const uint32_t *d_in, uint32_t *d_out, uint32_t log_m, uint32_t round,
+                    uint32_t beta_raw, void *stream);
+/* out[u * parts + q] = in[q * cnt + u]: cyclic <-> block layout around the all-to-all. */
+int zk_dev_interleave(const uint32_t *d_in, uint32_t *d_out, uint32_t log_parts, uint32_t log_cnt, void *stream);
+/* d_out[i*words ..] = d_src[d_offsets[i] .. + words]. */
+int zk_dev_gather(const uint32_t *d_src, const uint64_t *d_offsets, uint32_t count, uint32_t words,
+                  uint32_t *d_out, void *stream);
 /* d_vals: m u32 on the device; d_nodes: (2m-1)*8 u32 state words, heap order. */
 int zk_dev_merkle_build(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_nodes, void *stream);
 /* Byte view of nodes stored as state words: out[32] for node `index`. */

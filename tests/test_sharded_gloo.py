@@ -1,0 +1,94 @@
+"""The N > 1 path on CPU: world_size-2 and -4 gloo process groups run the sharded prover
+(zkstark_amd/sharded.py: the product's protocol and exchange logic) with the CPU test double as
+compute backend; the proof bytes must equal the single-process oracle's.  No GPU."""
+import hashlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, log_n, log_b, min_chunk_log, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from sharded_testlib import OracleBackend
+        from zkstark_amd import sharded
+        be = OracleBackend()
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(), be, min_chunk_log=min_chunk_log)
+        sp.trace_upload(oracle.trace_fibsq((1 << log_n) - 1))
+        proof = sp.prove()
+        q.put((rank, proof.data, proof.state, sp.n_sharded, dict(be.calls), [r.hex() for r in sp.transcript["roots"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, log_n, log_b, min_chunk_log):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, min_chunk_log, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(out)
+
+
+@pytest.mark.parametrize("world,log_n,log_b,min_chunk_log", [(2, 6, 3, 2), (4, 6, 3, 1), (2, 7, 2, 3), (2, 5, 1, 2), (8, 7, 3, 0)])
+def test_sharded_prover_matches_oracle(orc, world, log_n, log_b, min_chunk_log):
+    want = orc.prove(log_n, log_b)
+    assert want.rc == 0
+    res = _run(world, log_n, log_b, min_chunk_log)
+    for rank, data, state, n_sharded, calls, roots in res:
+        assert n_sharded >= 2, "the test must exercise sharded FRI layers"
+        assert roots == [bytes(r).hex() for r in want.roots], f"rank {rank}: roots differ"
+        assert data == want.proof and state == want.state, f"rank {rank}: proof differs from the oracle"
+        assert calls["lde"] == 1 and calls["compose"] == 1 and calls["fold"] == log_n
+    assert orc.verify(res[0][1], log_n, log_b, want.public_last) == 0
+
+
+def test_sharded_requires_world_dividing_blowup(zk):
+    from zkstark_amd import sharded
+
+    class FakeComm:
+        rank, world = 0, 4
+    with pytest.raises(zk.ZkError):
+        sharded.ShardedProver(6, 1, FakeComm(), backend=None)
+
+
+def test_path_nodes_and_host_top(orc):
+    """merkle.rs:54-71 index walk and the host top-of-tree agree with the oracle's full tree."""
+    from zkstark_amd import sharded
+    import numpy as np
+    vals = np.arange(16, dtype=np.uint32) * 7 + 1
+    nodes = orc.merkle_build(vals)
+    for leaf in range(16):
+        want = [bytes(h) for h in orc.merkle_trace(nodes, leaf)]
+        got = [bytes(nodes[j]) for j in sharded.path_nodes(16, leaf)]
+        assert got == want
+    # 4 subtrees of 4 leaves: top of their roots is the root of the whole tree
+    subroots = [bytes(orc.merkle_build(vals[4 * p:4 * p + 4])[0]) for p in range(4)]
+    top = sharded.host_merkle_top(subroots)
+    assert top[0] == bytes(nodes[0]) and top[1] == bytes(nodes[1]) and top[3:] == subroots

@@ -28,7 +28,7 @@ class TranscriptInfo(C.Structure):
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double), ("ops", C.c_double)]
 
 
 KERNEL_CLASSES = ("ntt", "merkle_leaf", "merkle_inner", "merkle_top", "compose", "fri_fold", "gather")
@@ -84,6 +84,15 @@ SYMBOLS = {
     "zk_merkle_build_host": (_int, [_int, _vp, _sz, _vp]),
     "zk_ntt_host": (_int, [_int, _vp, _u32, _int]),
     "zk_lde_host": (_int, [_int, _vp, _u32, _u32, _vp]),
+    "zk_dom_create": (_int, [_int, _u32, _u32, _u32, _int, C.POINTER(_vp)]),
+    "zk_dom_destroy": (_int, [_vp]),
+    "zk_dev_lde": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "zk_dev_compose": (_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp]),
+    "zk_dev_fri_fold": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    "zk_dev_interleave": (_int, [_vp, _vp, _u32, _u32, _vp]),
+    "zk_dev_gather": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "zk_dev_set_profiling": (_int, [_u32]),
+    "zk_dev_kernel_stats": (_int, [_vp, _sz, _int]),
     "zk_dev_merkle_build": (_int, [_vp, _u32, _vp, _vp]),
     "zk_dev_merkle_node": (_int, [_vp, _sz, _vp, _vp]),
 }
@@ -103,6 +112,14 @@ def load():
             raise ImportError(f"libzkstark_amd.so is missing and cannot be built: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise ImportError("libzkstark_amd.so is missing: run `python -m zkstark_amd.build` (needs hipcc)")
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    # libamdhip64.so.7); if it is loaded first the dynamic loader resolves this library's
+    # libamdhip64.so.7 to the same object, so torch tensors, streams and RCCL interoperate with
+    # the kernels here.  Loaded in the other order the process ends up with two runtimes.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export it

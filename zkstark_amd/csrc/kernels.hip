@@ -220,15 +220,14 @@ hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_
 // Composition
 // ===========================================================================
 
-// Context setup: inv_xm1[i] = 1/(w h^i - 1), Montgomery form.  Each thread inverts
+// Domain setup: inv_xm1[i] = 1/(shift h^i - 1), Montgomery form.  Each thread inverts
 // kInvBatch denominators with one Fermat inversion (Montgomery's trick).
 constexpr int kInvBatch = 8;
 
-__global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, uint32_t logN, PowTable htab) {
+__global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, uint32_t logN, PowTable htab, uint32_t w_mont) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t N = (size_t)1 << logN, base = gid * kInvBatch;
     if (base >= N) return;
-    const uint32_t w_mont = (uint32_t)(((uint64_t)GEN_W << 32) % P);
     uint32_t d[kInvBatch], pre[kInvBatch];
     uint32_t acc = R1;
 #pragma unroll
@@ -249,10 +248,10 @@ __global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, uint3
     }
 }
 
-hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, hipStream_t s) {
+hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s) {
     size_t N = (size_t)1 << logN, threads_total = (N + kInvBatch - 1) / kInvBatch;
     uint32_t blocks = (uint32_t)((threads_total + 255) / 256);
-    hipLaunchKernelGGL(build_inv_xm1_kernel, dim3(blocks), dim3(256), 0, s, out, logN, htab);
+    hipLaunchKernelGGL(build_inv_xm1_kernel, dim3(blocks), dim3(256), 0, s, out, logN, htab, shift_mont);
     return hipGetLastError();
 }
 
@@ -435,12 +434,16 @@ static double merkle_bytes(bool leaf, uint32_t depth, uint32_t k) {
     double produced = (leaf ? in : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k));
     return (leaf ? 4.0 : 32.0) * in + 32.0 * produced;
 }
+static double merkle_ops(bool leaf, uint32_t depth, uint32_t k) {
+    double in = (double)((size_t)1 << depth);
+    return (leaf ? in * kShaLeafOps : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k)) * kShaInnerOps;
+}
 
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof) {
     uint32_t depth = log_m;
     if (depth <= kMerkleTopLog) {
         size_t sh = ((size_t)2 << depth) * sizeof(uint4);
-        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(true, depth, depth), s);
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(true, depth, depth), s, merkle_ops(true, depth, depth));
         hipLaunchKernelGGL(merkle_top_kernel<true>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
         return hipGetLastError();
     }
@@ -453,15 +456,33 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         size_t lanes = (size_t)1 << (depth - k);
         uint32_t blocks = (uint32_t)((lanes + kMerkleThreads - 1) / kMerkleThreads);
         size_t sh = (size_t)k * 2 * kMerkleThreads * sizeof(uint4);
-        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s);
+        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s, merkle_ops(leaf, depth, k));
         if (leaf) hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
         else hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
         leaf = false;
         depth -= k;
     }
     size_t sh = ((size_t)2 << depth) * sizeof(uint4);
-    ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(false, depth, depth), s);
+    ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(false, depth, depth), s, merkle_ops(false, depth, depth));
     hipLaunchKernelGGL(merkle_top_kernel<false>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// Interleave (cyclic <-> block layout change around the multi-GPU exchange)
+// ===========================================================================
+// in: 2^log_parts pieces of 2^log_cnt words; out[u * parts + q] = in[q * cnt + u]
+__global__ void interleave_kernel(const uint32_t* in, uint32_t* out, uint32_t log_parts, uint32_t log_cnt) {
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= ((size_t)1 << (log_parts + log_cnt))) return;
+    size_t q = o & (((size_t)1 << log_parts) - 1), u = o >> log_parts;
+    out[o] = in[(q << log_cnt) + u];
+}
+
+hipError_t launch_interleave(const uint32_t* in, uint32_t* out, uint32_t log_parts, uint32_t log_cnt, hipStream_t s) {
+    size_t total = (size_t)1 << (log_parts + log_cnt);
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    hipLaunchKernelGGL(interleave_kernel, dim3(blocks), dim3(256), 0, s, in, out, log_parts, log_cnt);
     return hipGetLastError();
 }
 

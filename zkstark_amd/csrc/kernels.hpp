@@ -23,9 +23,12 @@ enum KernelClass : int {
     K_COUNT = 7
 };
 
+constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
+constexpr double kShaInnerOps = 2293.0;   // ... of one inner hash (two compressions, second with constant schedule)
+
 struct Profiler {
     uint32_t mask = 0;
-    struct Rec { int cls; hipEvent_t a, b; double bytes; };
+    struct Rec { int cls; hipEvent_t a, b; double bytes, ops; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
@@ -37,14 +40,15 @@ struct Profiler {
     bool on(int cls) const { return (mask >> cls) & 1u; }
 };
 
-// Brackets one kernel launch; bytes = algorithmic bytes of that launch.
+// Brackets one kernel launch; bytes = algorithmic bytes of that launch, ops = its compulsory
+// 32-bit VALU lane-ops (SHA-256 kernels; 0 elsewhere) -- DESIGN.md section 4.
 struct ScopedKernelTimer {
-    Profiler* p; int cls; double bytes; hipStream_t s; hipEvent_t a = nullptr;
-    ScopedKernelTimer(Profiler* p_, int cls_, double bytes_, hipStream_t s_) : p(p_), cls(cls_), bytes(bytes_), s(s_) {
+    Profiler* p; int cls; double bytes, ops; hipStream_t s; hipEvent_t a = nullptr;
+    ScopedKernelTimer(Profiler* p_, int cls_, double bytes_, hipStream_t s_, double ops_ = 0.0) : p(p_), cls(cls_), bytes(bytes_), ops(ops_), s(s_) {
         if (p && p->on(cls)) { a = p->get(); (void)hipEventRecord(a, s); }
     }
     ~ScopedKernelTimer() {
-        if (a) { hipEvent_t b = p->get(); (void)hipEventRecord(b, s); p->recs.push_back({cls, a, b, bytes}); }
+        if (a) { hipEvent_t b = p->get(); (void)hipEventRecord(b, s); p->recs.push_back({cls, a, b, bytes, ops}); }
     }
 };
 
@@ -89,8 +93,9 @@ hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Pr
 hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_m, uint32_t nd,
                                 const uint32_t* dig_bits, int to_natural, hipStream_t s);
 
-// inv_xm1[i] = 1 / (w h^i - 1) in Montgomery form, i < N (context setup)
-hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, hipStream_t s);
+// inv_xm1[i] = 1 / (shift h^i - 1) in Montgomery form, i < N (domain setup)
+hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s);
+hipError_t launch_interleave(const uint32_t* in, uint32_t* out, uint32_t log_parts, uint32_t log_cnt, hipStream_t s);
 
 struct ComposeArgs {
     const uint32_t* f;        // N canonical evaluations of the trace polynomial

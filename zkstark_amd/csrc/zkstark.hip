@@ -128,6 +128,144 @@ int run_dit(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw, uint32_
 }  // namespace
 
 // ===========================================================================
+// Coset evaluation domain: {shift * h^i, i < N}, h = root_of_unity(log_n + log_b)
+// ===========================================================================
+// Everything the kernels need that depends only on (log_n, log_b, shift): power tables,
+// the 1/(x-1) table, the transform plan and Montgomery constants.  The reference's
+// domain is shift = w = 5 (prover.rs:69).  A shard of a multi-GPU proof is the same
+// structure with shift = w * h_global^rank and a smaller blow-up.
+struct zk_dom {
+    int device = 0;
+    uint32_t log_n = 0, log_b = 0, L = 0;
+    size_t n = 0, N = 0, B = 0;
+    uint32_t shift = 0, g = 0, h = 0;
+    DevTable H, Hinv, W;
+    uint32_t* d_inv_xm1 = nullptr;   // null for fold-only domains
+    Plan plan;
+    uint32_t shift_mont = 0, gm1_mont = 0, gm2_mont = 0, gm3_mont = 0, ninv_mont = 0, inv2_mont = 0;
+    size_t device_bytes = 0;
+};
+
+namespace {
+
+void dom_free(zk_dom* d) {
+    if (!d) return;
+    free_table(&d->H); free_table(&d->Hinv); free_table(&d->W);
+    if (d->d_inv_xm1) (void)hipFree(d->d_inv_xm1);
+    delete d;
+}
+
+// fold_only: tables for fri_fold only (no w-power table, no 1/(x-1) table)
+int dom_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool fold_only, hipStream_t stream, zk_dom** out) {
+    *out = nullptr;
+    if (log_n < 1 || log_b > 5 || log_n + log_b > 30 || log_n + log_b < 1)
+        return fail(ZK_ERR_INVALID, "domain: need 1 <= log_n, log_blowup <= 5, log_n + log_blowup <= 30 (got %u, %u)", log_n, log_b);
+    if (shift == 0 || shift >= P) return fail(ZK_ERR_INVALID, "domain: shift must be a non-zero canonical residue");
+    HIPCHK(hipSetDevice(device));
+    zk_dom* d = new (std::nothrow) zk_dom();
+    if (!d) return fail(ZK_ERR_NOMEM, "out of host memory");
+    d->device = device;
+    d->log_n = log_n; d->log_b = log_b; d->L = log_n + log_b;
+    d->n = (size_t)1 << log_n; d->B = (size_t)1 << log_b; d->N = d->n << log_b;
+    d->shift = shift;
+    d->g = root_of_unity(log_n);
+    d->h = root_of_unity(d->L);
+    d->plan = make_plan(log_n);
+    int rc;
+    if ((rc = build_table(d->h, d->L, &d->H)) || (rc = build_table(invmod(d->h), d->L, &d->Hinv))) { dom_free(d); return rc; }
+    uint32_t gm1 = invmod(d->g);
+    d->shift_mont = to_mont(shift);
+    d->gm1_mont = to_mont(gm1);
+    d->gm2_mont = to_mont(mulmod(gm1, gm1));
+    d->gm3_mont = to_mont(mulmod(mulmod(gm1, gm1), gm1));
+    d->ninv_mont = to_mont(invmod((uint32_t)(d->n % P)));
+    d->inv2_mont = to_mont(invmod(2));
+    if (!fold_only) {
+        if ((rc = build_table(shift, log_n, &d->W))) { dom_free(d); return rc; }
+        // x_i - 1 must be invertible on the whole domain: shift^N != 1
+        if (powmod(shift, d->N) == 1) { dom_free(d); return fail(ZK_ERR_INVALID, "domain: shift lies in the evaluation subgroup"); }
+        hipError_t e = hipMalloc((void**)&d->d_inv_xm1, d->N * 4);
+        if (e != hipSuccess) { dom_free(d); return fail(ZK_ERR_NOMEM, "hipMalloc(%zu) failed", d->N * 4); }
+        d->device_bytes += d->N * 4;
+        e = launch_build_inv_xm1(d->d_inv_xm1, d->L, d->H.view(), d->shift_mont, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { dom_free(d); return fail(ZK_ERR_HIP, "inv_xm1 build failed: %s", hipGetErrorString(e)); }
+    }
+    *out = d;
+    return ZK_OK;
+}
+
+// lagrange + solve over the coset (polynomial.rs:337, :49; prover.rs:60-70).
+// d_trace: n words (a[0..n-2], 0); d_coef: n words scratch; d_out: N words.
+int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t* d_out, hipStream_t s, Profiler* prof) {
+    // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
+    int rc = run_dif(d_trace, d_coef, d->log_n, d->plan, d->Hinv.view(), d->L, 0, s, prof);
+    if (rc) return rc;
+    // size-N forward transform of the zero-padded, shift^k-scaled coefficients
+    uint32_t inner = d->log_b;
+    for (int q = (int)d->plan.nd - 1; q >= 0; --q) {
+        NttPassArgs a{};
+        a.log_total = d->L; a.logR = d->plan.bits[q]; a.logS = inner; a.logC = pick_logC(d->L, a.logR);
+        a.L = d->L; a.tw = d->H.view();
+        a.dst = d_out;
+        if (q == (int)d->plan.nd - 1) {
+            if (a.logC < d->log_b) a.logC = d->log_b;
+            a.src = d_coef;
+            a.wtab = d->W.view(); a.log_n = d->log_n; a.ninv_mont = d->ninv_mont;
+            a.nd = d->plan.nd;
+            for (uint32_t t = 0; t < d->plan.nd; ++t) a.dig_bits[t] = d->plan.bits[t];
+            HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, s, prof));
+        } else {
+            a.src = d_out;
+            HIPCHK(launch_ntt_pass(a, NTT_DIT, s, prof));
+        }
+        inner += d->plan.bits[q];
+    }
+    return ZK_OK;
+}
+
+// prover.rs:101-173 pointwise on the domain.
+int dom_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last,
+                const uint32_t alpha_raw[3], hipStream_t s, Profiler* prof) {
+    ComposeArgs a{};
+    a.f = d_f; a.inv_xm1 = d->d_inv_xm1; a.cp = d_cp;
+    a.logN = d->L; a.log_b = d->log_b;
+    a.htab = d->H.view();
+    a.w_mont = d->shift_mont; a.gm1_mont = d->gm1_mont; a.gm2_mont = d->gm2_mont; a.gm3_mont = d->gm3_mont;
+    a.first = first % P; a.last = last % P;
+    uint32_t a0 = alpha_raw[0] % P, a1 = alpha_raw[1] % P, a2 = alpha_raw[2] % P;   // field.rs:20-24
+    a.alpha0_mont = to_mont(a0);
+    a.alpha1g2_mont = to_mont(mulmod(a1, mulmod(d->g, d->g)));
+    // x^n on the domain takes B values: (shift h^i)^n = shift^n (h^n)^(i mod B)
+    uint32_t xn = powmod(d->shift, d->n), hn = powmod(d->h, d->n);
+    for (size_t r = 0; r < d->B; ++r) {
+        uint32_t den = sub(xn, 1);
+        if (den == 0) return fail(ZK_ERR_INVALID, "compose: x^n = 1 on the domain");
+        a.zz[r] = to_mont(to_mont(mulmod(a2, invmod(den))));
+        xn = mulmod(xn, hn);
+    }
+    HIPCHK(launch_compose(a, s, prof));
+    return ZK_OK;
+}
+
+// polynomial.rs:385-400 + prover.rs:204-211 in evaluation form: layer of 2^log_m values at
+// x_i = (shift h^i)^(2^round) -> 2^(log_m-1) values.
+int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw,
+             hipStream_t s, Profiler* prof) {
+    if (log_m < 1 || log_m + round != d->L) return fail(ZK_ERR_INVALID, "fold: layer size 2^%u does not match round %u of a 2^%u domain", log_m, round, d->L);
+    FoldArgs a{};
+    a.in = d_in; a.out = d_out; a.log_m = log_m; a.round = round;
+    a.hinv = d->Hinv.view(); a.L = d->L;
+    a.inv2_mont = d->inv2_mont;
+    uint32_t winv = invmod(powmod(d->shift, (uint64_t)1 << round));
+    a.c_mont = to_mont(mulmod(mulmod(beta_raw % P, winv), invmod(2)));
+    HIPCHK(launch_fri_fold(a, s, prof));
+    return ZK_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
 // Context
 // ===========================================================================
 struct zk_ctx {
@@ -136,9 +274,7 @@ struct zk_ctx {
     size_t n = 0, N = 0, B = 0;
     uint32_t R = 0;   // FRI rounds = log_n (prover.rs:198)
     hipStream_t stream = nullptr;
-    DevTable H, Hinv, W;
-    uint32_t* d_inv_xm1 = nullptr;
-    Plan plan;
+    zk_dom* dom = nullptr;
     uint32_t* d_trace = nullptr;    // n words: a[0..n-2], 0   (stays resident across proofs)
     uint32_t* d_coef = nullptr;     // n words: interpolant coefficients, digit-reversed order
     uint32_t* d_layers = nullptr;   // layer 0 (N) | layer 1 (N) | layer 2 (N/2) | ... | layer R+1 (B)
@@ -153,9 +289,6 @@ struct zk_ctx {
     size_t gather_cap = 0;
     size_t device_bytes = 0;
     double setup_ms = 0;
-    // constants (Montgomery)
-    uint32_t w_mont = 0, gm1_mont = 0, gm2_mont = 0, gm3_mont = 0, ninv_mont = 0, inv2_mont = 0;
-    uint32_t g = 0, h = 0;
     // per-proof state
     bool have_trace = false, have_lde = false;
     uint32_t first = 0, last = 0;
@@ -188,6 +321,7 @@ void collect_kernel_stats(zk_ctx* c) {
         c->kstat[r.cls].launches += 1;
         c->kstat[r.cls].ms += ms;
         c->kstat[r.cls].bytes += r.bytes;
+        c->kstat[r.cls].ops += r.ops;
         c->prof.pool.push_back(r.a);
         c->prof.pool.push_back(r.b);
     }
@@ -195,32 +329,9 @@ void collect_kernel_stats(zk_ctx* c) {
 }
 
 int do_lde(zk_ctx* c) {
-    // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
-    int rc = run_dif(c->d_trace, c->d_coef, c->log_n, c->plan, c->Hinv.view(), c->L, 0, c->stream, prof_of(c));
-    if (rc) return rc;
-    // size-N forward transform of the zero-padded, w^k-scaled coefficients
-    uint32_t* f = c->d_layers + c->layer_off[0];
-    uint32_t inner = c->log_b;
-    for (int d = (int)c->plan.nd - 1; d >= 0; --d) {
-        NttPassArgs a{};
-        a.log_total = c->L; a.logR = c->plan.bits[d]; a.logS = inner; a.logC = pick_logC(c->L, a.logR);
-        a.L = c->L; a.tw = c->H.view();
-        a.dst = f;
-        if (d == (int)c->plan.nd - 1) {
-            if (a.logC < c->log_b) a.logC = c->log_b;
-            a.src = c->d_coef;
-            a.wtab = c->W.view(); a.log_n = c->log_n; a.ninv_mont = c->ninv_mont;
-            a.nd = c->plan.nd;
-            for (uint32_t q = 0; q < c->plan.nd; ++q) a.dig_bits[q] = c->plan.bits[q];
-            HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, c->stream, prof_of(c)));
-        } else {
-            a.src = f;
-            HIPCHK(launch_ntt_pass(a, NTT_DIT, c->stream, prof_of(c)));
-        }
-        inner += c->plan.bits[d];
-    }
-    c->have_lde = true;
-    return ZK_OK;
+    int rc = dom_lde(c->dom, c->d_trace, c->d_coef, c->d_layers + c->layer_off[0], c->stream, prof_of(c));
+    if (!rc) c->have_lde = true;
+    return rc;
 }
 
 int do_merkle(zk_ctx* c, uint32_t layer) {
@@ -230,41 +341,13 @@ int do_merkle(zk_ctx* c, uint32_t layer) {
 }
 
 int do_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
-    ComposeArgs a{};
-    a.f = c->d_layers + c->layer_off[0];
-    a.inv_xm1 = c->d_inv_xm1;
-    a.cp = c->d_layers + c->layer_off[1];
-    a.logN = c->L; a.log_b = c->log_b;
-    a.htab = c->H.view();
-    a.w_mont = c->w_mont; a.gm1_mont = c->gm1_mont; a.gm2_mont = c->gm2_mont; a.gm3_mont = c->gm3_mont;
-    a.first = c->first; a.last = c->last;
-    uint32_t a0 = alpha_raw[0] % P, a1 = alpha_raw[1] % P, a2 = alpha_raw[2] % P;   // field.rs:20-24
-    a.alpha0_mont = to_mont(a0);
-    a.alpha1g2_mont = to_mont(mulmod(a1, mulmod(c->g, c->g)));
-    // x^n on the coset takes B values: (w h^i)^n = w^n (h^n)^(i mod B)
-    uint32_t xn = powmod(GEN_W, c->n), hn = powmod(c->h, c->n);
-    for (size_t r = 0; r < c->B; ++r) {
-        uint32_t zinv = invmod(sub(xn, 1));
-        a.zz[r] = to_mont(to_mont(mulmod(a2, zinv)));
-        xn = mulmod(xn, hn);
-    }
-    HIPCHK(launch_compose(a, c->stream, prof_of(c)));
-    return ZK_OK;
+    return dom_compose(c->dom, c->d_layers + c->layer_off[0], c->d_layers + c->layer_off[1], c->first, c->last,
+                       alpha_raw, c->stream, prof_of(c));
 }
 
 int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
-    FoldArgs a{};
-    a.in = c->d_layers + c->layer_off[1 + round];
-    a.out = c->d_layers + c->layer_off[2 + round];
-    a.log_m = c->L - round;
-    a.round = round;
-    a.hinv = c->Hinv.view();
-    a.L = c->L;
-    a.inv2_mont = c->inv2_mont;
-    uint32_t winv = invmod(powmod(GEN_W, (uint64_t)1 << round));
-    a.c_mont = to_mont(mulmod(mulmod(beta_raw % P, winv), invmod(2)));
-    HIPCHK(launch_fri_fold(a, c->stream, prof_of(c)));
-    return ZK_OK;
+    return dom_fold(c->dom, c->d_layers + c->layer_off[1 + round], c->d_layers + c->layer_off[2 + round],
+                    c->L - round, round, beta_raw, c->stream, prof_of(c));
 }
 
 int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
@@ -406,9 +489,6 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     c->log_n = log_n; c->log_b = log_b; c->L = log_n + log_b;
     c->n = (size_t)1 << log_n; c->B = (size_t)1 << log_b; c->N = c->n << log_b;
     c->R = log_n;
-    c->plan = make_plan(log_n);
-    c->g = root_of_unity(log_n);
-    c->h = root_of_unity(c->L);
     int rc = ZK_OK;
     auto bail = [&](int code) { zk_ctx_destroy(c); return code; };
 #define HIPCHK_C(expr)                                                                        \
@@ -420,16 +500,8 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
         }                                                                                     \
     } while (0)
     HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if ((rc = build_table(c->h, c->L, &c->H))) return bail(rc);
-    if ((rc = build_table(invmod(c->h), c->L, &c->Hinv))) return bail(rc);
-    if ((rc = build_table(GEN_W, log_n, &c->W))) return bail(rc);
-    uint32_t gm1 = invmod(c->g);
-    c->w_mont = to_mont(GEN_W);
-    c->gm1_mont = to_mont(gm1);
-    c->gm2_mont = to_mont(mulmod(gm1, gm1));
-    c->gm3_mont = to_mont(mulmod(mulmod(gm1, gm1), gm1));
-    c->ninv_mont = to_mont(invmod((uint32_t)(c->n % P)));
-    c->inv2_mont = to_mont(invmod(2));
+    if ((rc = dom_make(device, log_n, log_b, GEN_W, false, c->stream, &c->dom))) return bail(rc);
+    c->device_bytes += c->dom->device_bytes;
     // layers: 0 = f_eval (N), 1 + r = FRI layer r (N >> r), r = 0 .. R
     size_t off = 0;
     for (uint32_t l = 0; l <= c->R + 1; ++l) {
@@ -448,15 +520,12 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     if ((rc = dmalloc(c, &c->d_coef, c->n * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_layers, layer_words * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_trees, tree_words * 4))) return bail(rc);
-    if ((rc = dmalloc(c, &c->d_inv_xm1, c->N * 4))) return bail(rc);
     c->gather_cap = (size_t)(4 + 2 * c->R) * (c->L + 1) + 64;
     if ((rc = dmalloc(c, &c->d_gather_off, c->gather_cap * 8))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_gather_out, c->gather_cap * 32))) return bail(rc);
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8));
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_out, c->gather_cap * 32));
     HIPCHK_C(hipHostMalloc((void**)&c->h_small, 4096));
-    HIPCHK_C(launch_build_inv_xm1(c->d_inv_xm1, c->L, c->H.view(), c->stream));
-    HIPCHK_C(hipStreamSynchronize(c->stream));
 #undef HIPCHK_C
     c->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = c;
@@ -467,8 +536,7 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (!c) return ZK_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    free_table(&c->H); free_table(&c->Hinv); free_table(&c->W);
-    if (c->d_inv_xm1) (void)hipFree(c->d_inv_xm1);
+    dom_free(c->dom);
     if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_coef) (void)hipFree(c->d_coef);
     if (c->d_layers) (void)hipFree(c->d_layers);
@@ -685,10 +753,69 @@ int zk_channel_data(const zk_channel* ch, uint8_t* out, size_t cap) {
     return ZK_OK;
 }
 
+// ---- domains and device-pointer primitives ------------------------------------------
+static Profiler g_dev_prof;                    // optional timing of the zk_dev_* launches
+static zk_kernel_stat g_dev_kstat[K_COUNT] = {};
+static Profiler* dev_prof() { return g_dev_prof.mask ? &g_dev_prof : nullptr; }
+
+int zk_dev_set_profiling(uint32_t class_mask) {
+    g_dev_prof.mask = class_mask & ((1u << K_COUNT) - 1u);
+    return ZK_OK;
+}
+int zk_dev_kernel_stats(zk_kernel_stat* out, size_t count, int reset) {
+    if (!out && count) return fail(ZK_ERR_INVALID, "zk_dev_kernel_stats: null argument");
+    for (auto& r : g_dev_prof.recs) {
+        float ms = 0;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        g_dev_kstat[r.cls].launches += 1; g_dev_kstat[r.cls].ms += ms; g_dev_kstat[r.cls].bytes += r.bytes; g_dev_kstat[r.cls].ops += r.ops;
+        g_dev_prof.pool.push_back(r.a); g_dev_prof.pool.push_back(r.b);
+    }
+    g_dev_prof.recs.clear();
+    for (size_t i = 0; i < count && i < (size_t)K_COUNT; ++i) out[i] = g_dev_kstat[i];
+    if (reset) for (int i = 0; i < K_COUNT; ++i) g_dev_kstat[i] = zk_kernel_stat{};
+    return ZK_OK;
+}
+
+int zk_dom_create(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, int fold_only, zk_dom** out) {
+    if (!out) return fail(ZK_ERR_INVALID, "zk_dom_create: out is null");
+    return dom_make(device, log_n, log_b, shift, fold_only != 0, nullptr, out);
+}
+int zk_dom_destroy(zk_dom* d) {
+    if (d) { (void)hipSetDevice(d->device); dom_free(d); }
+    return ZK_OK;
+}
+int zk_dev_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t* d_out, void* stream) {
+    if (!d || !d_trace || !d_coef || !d_out) return fail(ZK_ERR_INVALID, "zk_dev_lde: null argument");
+    if (!d->d_inv_xm1) return fail(ZK_ERR_STATE, "zk_dev_lde: fold-only domain");
+    return dom_lde(d, d_trace, d_coef, d_out, (hipStream_t)stream, dev_prof());
+}
+int zk_dev_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last,
+                   const uint32_t alpha_raw[3], void* stream) {
+    if (!d || !d_f || !d_cp || !alpha_raw) return fail(ZK_ERR_INVALID, "zk_dev_compose: null argument");
+    if (!d->d_inv_xm1) return fail(ZK_ERR_STATE, "zk_dev_compose: fold-only domain");
+    return dom_compose(d, d_f, d_cp, first, last, alpha_raw, (hipStream_t)stream, dev_prof());
+}
+int zk_dev_fri_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round,
+                    uint32_t beta_raw, void* stream) {
+    if (!d || !d_in || !d_out) return fail(ZK_ERR_INVALID, "zk_dev_fri_fold: null argument");
+    return dom_fold(d, d_in, d_out, log_m, round, beta_raw, (hipStream_t)stream, dev_prof());
+}
+int zk_dev_interleave(const uint32_t* d_in, uint32_t* d_out, uint32_t log_parts, uint32_t log_cnt, void* stream) {
+    if (!d_in || !d_out || log_parts + log_cnt > 31) return fail(ZK_ERR_INVALID, "zk_dev_interleave: bad argument");
+    HIPCHK(launch_interleave(d_in, d_out, log_parts, log_cnt, (hipStream_t)stream));
+    return ZK_OK;
+}
+int zk_dev_gather(const uint32_t* d_src, const uint64_t* d_offsets, uint32_t count, uint32_t words, uint32_t* d_out, void* stream) {
+    if (!d_src || (!d_offsets && count) || (!d_out && count)) return fail(ZK_ERR_INVALID, "zk_dev_gather: null argument");
+    HIPCHK(launch_gather(d_src, d_offsets, count, words, d_out, (hipStream_t)stream, dev_prof()));
+    return ZK_OK;
+}
+
 // ---- stand-alone primitives --------------------------------------------------------
 int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
     if (!d_vals || !d_nodes || log_m > 30) return fail(ZK_ERR_INVALID, "zk_dev_merkle_build: bad argument");
-    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream));
+    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream, dev_prof()));
     return ZK_OK;
 }
 

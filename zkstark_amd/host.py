@@ -215,7 +215,7 @@ class Context:
     def kernel_stats(self, reset=True):
         arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
         check(_lib.load().zk_kernel_stats(self._h, arr, len(arr), int(reset)))
-        return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes}
+        return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes, "ops": a.ops}
                 for name, a in zip(_lib.KERNEL_CLASSES, arr)}
 
     def layer_size(self, layer): return self.N if layer == 0 else self.N >> (layer - 1)

@@ -1,0 +1,431 @@
+"""Sharded prover: one proof across G GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Layout.  The evaluation domain is distributed CYCLICALLY: rank r holds the
+elements i = r (mod G) of every layer.  Rank r's shard of the size-N coset {w h^i} is itself a
+coset domain {(w h^r) (h^G)^j, j < N/G} with blow-up B/G, so
+
+  * LDE          rank r evaluates its B/G cosets of the (replicated) size-n interpolant,
+  * composition  taps i+B, i+2B are local (G divides B),
+  * FRI fold     pairs (i, i+m/2) are local, and the folded layer is again cyclic,
+
+all with no communication, using the same kernels as the single-GPU path on a domain with
+shift w h^r.  The only exchange step is the commitment: Merkle leaves are in natural order, so
+per committed layer ONE all-to-all of the 4-byte values turns the cyclic layout into contiguous
+blocks of m/G leaves, each rank hashes its subtree, the G subtree roots (32 B each) are
+all-gathered and the top log2(G) levels are hashed on the host by every rank.  Once a layer has
+fewer than 2^min_chunk_log leaves per (rank, peer) chunk it is all-gathered once and the
+remaining small layers are folded and committed redundantly on every rank.  The transcript
+(channel.rs) runs identically on every rank, so challenges are never broadcast.  No all-reduce.
+
+Collectives per proof: (number of sharded layers + 1) all-to-alls, as many 256-byte
+all-gathers, one all-gather for the replication switch and one for the decommitment.
+
+The protocol logic lives here and is shared by two compute backends with the same interface:
+`HipBackend` (the product: gfx950 kernels through the C ABI on torch CUDA tensors) and a CPU
+test double that tests inject (tests/test_sharded_gloo.py); there is no CPU fallback in this file.
+"""
+import ctypes as C
+import hashlib
+import struct
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import ZkError, check
+from .host import Channel, Proof, P, trace_fibsq
+
+GEN_W = 5
+
+
+def _pow(a, e):
+    return pow(int(a), int(e), P)
+
+
+def root_of_unity(log_order):
+    return _pow(GEN_W, (P - 1) >> log_order)
+
+
+# merkle.rs:54-71: node indices of the authentication path of `leaf` in a heap of m leaves
+def path_nodes(m, leaf):
+    i = leaf + (2 * m - 1) // 2
+    out = []
+    while i != 0:
+        if i % 2 == 0:
+            out.append(i - 1); i -= 2
+        else:
+            out.append(i + 1); i -= 1
+        i >>= 1
+    return out
+
+
+def host_merkle_top(subroots):
+    """merkle.rs:38-47 over G subtree roots (bytes): returns the heap of 2G-1 digests, root first."""
+    g = len(subroots)
+    heap = [None] * (2 * g - 1)
+    heap[g - 1:] = list(subroots)
+    for j in range(g - 2, -1, -1):
+        heap[j] = hashlib.sha256(heap[2 * j + 1] + heap[2 * j + 2]).digest()
+    return heap
+
+
+def words_to_bytes(words):
+    """Digest state words (native u32) -> SHA-256 byte order."""
+    return np.ascontiguousarray(words, dtype=np.uint32).astype(">u4").tobytes()
+
+
+class Comm:
+    """The three collectives the path needs, over torch.distributed.  `staged` moves device tensors
+    through host memory (gloo); with the nccl backend (RCCL) tensors are exchanged in place."""
+
+    def __init__(self, group=None, staged=False):
+        import torch.distributed as dist
+        self.dist, self.group, self.staged = dist, group, staged
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_to_all(self, send, recv):
+        """Equal splits: chunk p of `send` goes to rank p; chunk q of `recv` comes from rank q."""
+        if self.staged and send.is_cuda:
+            s, r = send.cpu(), recv.cpu()
+            self.dist.all_to_all_single(r, s, group=self.group)
+            recv.copy_(r)
+        else:
+            self.dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def all_gather(self, t, out):
+        """out: [world * len(t)] flat."""
+        if self.staged and t.is_cuda:
+            o = out.cpu()
+            self.dist.all_gather_into_tensor(o, t.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+
+class LocalComm:
+    """world = 1 (no process group): lets the sharded code path run in a single process."""
+    rank, world = 0, 1
+
+
+class HipBackend:
+    """gfx950 kernels through the C ABI (include/zkstark_amd.h, zk_dev_*), on torch CUDA tensors,
+    enqueued on torch's current stream so that RCCL collectives order with them."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.index = device
+        self.lib = _lib.load()
+        self._doms = []
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def domain(self, log_n, log_b, shift, fold_only=False):
+        h = C.c_void_p()
+        check(self.lib.zk_dom_create(self.index, log_n, log_b, shift, int(fold_only), C.byref(h)))
+        self._doms.append(h)
+        return h
+
+    def close(self):
+        for h in self._doms:
+            self.lib.zk_dom_destroy(h)
+        self._doms = []
+
+    def empty(self, nwords):
+        return self.torch.empty(nwords, dtype=self.torch.int32, device=self.device)
+
+    def upload(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint32).view(np.int32)).to(self.device)
+
+    def lde(self, dom, trace, coef, out):
+        check(self.lib.zk_dev_lde(dom, trace.data_ptr(), coef.data_ptr(), out.data_ptr(), self._stream()))
+
+    def compose(self, dom, f, cp, first, last, alphas):
+        a = (C.c_uint32 * 3)(*alphas)
+        check(self.lib.zk_dev_compose(dom, f.data_ptr(), cp.data_ptr(), first, last, a, self._stream()))
+
+    def fold(self, dom, src, dst, log_m, rnd, beta):
+        check(self.lib.zk_dev_fri_fold(dom, src.data_ptr(), dst.data_ptr(), log_m, rnd, beta, self._stream()))
+
+    def interleave(self, src, dst, log_parts, log_cnt):
+        check(self.lib.zk_dev_interleave(src.data_ptr(), dst.data_ptr(), log_parts, log_cnt, self._stream()))
+
+    def merkle(self, vals, log_m, nodes):
+        check(self.lib.zk_dev_merkle_build(vals.data_ptr(), log_m, nodes.data_ptr(), self._stream()))
+
+    def gather(self, src, offsets, words):
+        """Returns a host uint32 array [len(offsets), words]."""
+        torch = self.torch
+        off = torch.from_numpy(np.asarray(offsets, dtype=np.int64)).to(self.device)
+        out = torch.empty(len(offsets) * words, dtype=torch.int32, device=self.device)
+        check(self.lib.zk_dev_gather(src.data_ptr(), off.data_ptr(), len(offsets), words, out.data_ptr(), self._stream()))
+        return out
+
+    def to_host(self, t):
+        return t.cpu().numpy().view(np.uint32)
+
+    def sync(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+
+class ShardedProver:
+    """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
+
+    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=10):
+        self.log_n, self.log_b, self.comm, self.be = log_n, log_blowup, comm, backend
+        G = comm.world
+        self.G, self.rank = G, comm.rank
+        self.lg = G.bit_length() - 1
+        if 1 << self.lg != G or self.lg > log_blowup:
+            raise ZkError(-1, f"world size {G} must be a power of two dividing the blow-up {1 << log_blowup}")
+        self.L = log_n + log_blowup
+        self.R = log_n
+        self.n, self.N, self.B = 1 << log_n, 1 << self.L, 1 << log_blowup
+        # FRI layer rho (2^(L-rho) values) stays sharded while a (rank, peer) chunk has >= 2^min_chunk_log leaves
+        self.n_sharded = sum(1 for rho in range(self.R + 1) if self.L - rho - 2 * self.lg >= min_chunk_log)
+        if self.n_sharded < 1:
+            raise ZkError(-1, "domain too small to shard: use the single-GPU prover")
+        h = root_of_unity(self.L)
+        self.shift = GEN_W * _pow(h, self.rank) % P
+        be = self.be
+        self.dom_loc = be.domain(log_n, log_blowup - self.lg, self.shift)
+        self.dom_glob = be.domain(log_n, log_blowup, GEN_W, fold_only=True) if self.n_sharded <= self.R else None
+        # one allocation for layers, one for trees (as the single-GPU context)
+        NL = self.N // G
+        self.layer_off, self.layer_len, off = [], [], 0
+        sizes = [NL] + [self._layer_words(rho) for rho in range(self.R + 1)]
+        for s in sizes:
+            self.layer_off.append(off); self.layer_len.append(s); off += s
+        self.layers = be.empty(off)
+        self.tree_off, off = [], 0
+        for t in range(self.R + 2):
+            self.tree_off.append(off)
+            off += (2 * self._tree_leaves(t) - 1) * 8
+        self.trees = be.empty(off)
+        self.trace = be.empty(self.n)
+        self.coef = be.empty(self.n)
+        self.recv = be.empty(NL)
+        self.block = be.empty(NL)
+        self.subroot_all = be.empty(8 * G)
+        # the first replicated layer arrives as G cyclic pieces before it is interleaved
+        self.gbuf = be.empty(max(1, self.N >> self.n_sharded)) if self.n_sharded <= self.R else None
+        self.have_trace = False
+
+    # layer ids: 0 = f, 1 + rho = FRI layer rho
+    def _sharded(self, rho):
+        return rho < self.n_sharded
+
+    def _layer_words(self, rho):
+        m = self.N >> rho
+        return m // self.G if self._sharded(rho) else m
+
+    def _tree_leaves(self, t):
+        if t == 0:
+            return self.N // self.G
+        m = self.N >> (t - 1)
+        return m // self.G if self._sharded(t - 1) else m
+
+    def _layer(self, lid):
+        return self.layers[self.layer_off[lid]:self.layer_off[lid] + self.layer_len[lid]]
+
+    def _tree(self, t):
+        return self.trees[self.tree_off[t]:self.tree_off[t] + (2 * self._tree_leaves(t) - 1) * 8]
+
+    def trace_upload(self, trace):
+        t = np.ascontiguousarray(trace, dtype=np.uint32)
+        if len(t) != self.n - 1:
+            raise ZkError(-1, f"expected n-1 = {self.n - 1} trace values")
+        self.trace.copy_(self.be.upload(np.concatenate([t, np.zeros(1, dtype=np.uint32)])))
+        self.first, self.last = int(t[0]), int(t[-1])
+        self.have_trace = True
+
+    # ---- commitments ----------------------------------------------------------------------
+    def _commit_sharded(self, lid, m_log):
+        """Cyclic layer of 2^m_log values in total -> subtree over this rank's block; returns the root."""
+        be, G, lg = self.be, self.G, self.lg
+        loc = self._layer(lid)
+        cnt = loc.numel()
+        recv, block = self.recv[:cnt], self.block[:cnt]
+        if G > 1:
+            self.comm.all_to_all(loc, recv)                       # chunk q: rank q's j in my block
+            be.interleave(recv, block, lg, m_log - 2 * lg)        # block[u*G + q] = recv[q][u]
+        else:
+            block = loc
+        nodes = self._tree(lid)
+        be.merkle(block, m_log - lg, nodes)
+        if G > 1:
+            self.comm.all_gather(nodes[:8], self.subroot_all)
+            words = be.to_host(self.subroot_all).reshape(G, 8)
+        else:
+            words = be.to_host(nodes[:8]).reshape(1, 8)
+        top = host_merkle_top([words_to_bytes(w) for w in words])
+        self.tops[lid] = top
+        return top[0]
+
+    def _commit_replicated(self, lid, m_log):
+        nodes = self._tree(lid)
+        self.be.merkle(self._layer(lid), m_log, nodes)
+        return words_to_bytes(self.be.to_host(nodes[:8]))
+
+    # ---- the prover ---------------------------------------------------------------------------
+    def prove(self):
+        if not self.have_trace:
+            raise ZkError(-4, "no trace uploaded")
+        be, G, lg, L, R, B, N = self.be, self.G, self.lg, self.L, self.R, self.B, self.N
+        ch = Channel()
+        self.tops = {}
+        roots = []
+        be.lde(self.dom_loc, self.trace, self.coef, self._layer(0))                 # prover.rs:60-70
+        roots.append(self._commit_sharded(0, L)); ch.commit(roots[-1])              # prover.rs:81-85
+        alphas = [ch.get_u32() for _ in range(3)]                                   # prover.rs:163-165
+        be.compose(self.dom_loc, self._layer(0), self._layer(1), self.first, self.last, alphas)   # :166-173
+        roots.append(self._commit_sharded(1, L)); ch.commit(roots[-1])              # prover.rs:176-180
+        betas = []
+        for rho in range(R):                                                        # prover.rs:198-225
+            beta = ch.get_u32(); betas.append(beta)
+            m_log = L - rho
+            src, dst_id = self._layer(1 + rho), 2 + rho
+            if self._sharded(rho + 1):
+                be.fold(self.dom_loc, src, self._layer(dst_id), m_log - lg, rho, beta)
+                root = self._commit_sharded(dst_id, m_log - 1)
+            elif self._sharded(rho):
+                # replication switch: fold locally, all-gather the G cyclic pieces, interleave to natural order
+                cnt = (1 << (m_log - 1)) // G
+                piece = self.recv[:cnt]
+                be.fold(self.dom_loc, src, piece, m_log - lg, rho, beta)
+                if G > 1:
+                    gathered = self.gbuf[:cnt * G]
+                    self.comm.all_gather(piece, gathered)
+                    be.interleave(gathered, self._layer(dst_id), lg, m_log - 1 - lg)
+                else:
+                    self._layer(dst_id).copy_(piece)
+                root = self._commit_replicated(dst_id, m_log - 1)
+            else:
+                be.fold(self.dom_glob, src, self._layer(dst_id), m_log, rho, beta)
+                root = self._commit_replicated(dst_id, m_log - 1)
+            roots.append(root); ch.commit(root)                                     # prover.rs:224
+        # last layer: B equal values (prover.rs:238, :251, :254)
+        if self._sharded(R):
+            raise ZkError(-4, "last FRI layer still sharded: lower min_chunk_log only with a tiny world")
+        last = be.to_host(self._layer(1 + R))
+        if not (last == last[0]).all():
+            raise ZkError(-7, "last FRI layer is not constant (prover.rs:238)")
+        free_term = int(last[0])
+        ch.commit(free_term)                                                        # prover.rs:254
+        x = ch.get_u32() % (N - 2 * B)                                              # prover.rs:263
+        self.transcript = {"alpha_raw": alphas, "beta_raw": betas, "roots": roots, "free_term": free_term, "query": x}
+        self._decommit(ch, x)
+        return Proof(ch.state, ch.data, self.log_n, self.log_b, self.last)
+
+    def _decommit(self, ch, x):
+        """prover.rs:266-289.  Every rank gathers the slots it owns (same slot list everywhere), one
+        all-gather merges them, every rank assembles the same bytes."""
+        be, G, lg, L, R, B, N = self.be, self.G, self.lg, self.L, self.R, self.B, self.N
+        val_items, dig_items = [], []      # (owner or -1, offset)
+        openings = []                      # (lid, leaf, m_log, n_local_digests, top_path or None)
+
+        def add_opening(lid, leaf, m_log, sharded):
+            if sharded:
+                owner_v, off_v = leaf % G, self.layer_off[lid] + leaf // G
+                blk = (1 << m_log) // G
+                p, lf = leaf // blk, leaf % blk
+                nodes = path_nodes(blk, lf)
+                for nd in nodes:
+                    dig_items.append((p, self.tree_off[lid] + nd * 8))
+                top_path = [self.tops[lid][j] for j in path_nodes(G, p)]
+            else:
+                owner_v, off_v = -1, self.layer_off[lid] + leaf
+                nodes = path_nodes(1 << m_log, leaf)
+                for nd in nodes:
+                    dig_items.append((-1, self.tree_off[lid] + nd * 8))
+                top_path = []
+            val_items.append((owner_v, off_v))
+            openings.append((len(nodes), top_path))
+
+        for lid, leaf in ((0, x), (0, x + B), (0, x + 2 * B), (1, x)):               # prover.rs:266-277
+            add_opening(lid, leaf, L, True)
+        for i in range(R):                                                            # prover.rs:280-289
+            ln = N >> i
+            xi = x % ln
+            nx = (xi + ln // 2) % ln
+            add_opening(1 + i, xi, L - i, self._sharded(i))
+            add_opening(1 + i, nx, L - i, self._sharded(i))
+        me = self.rank
+        voff = [off if o in (-1, me) else 0 for o, off in val_items]
+        doff = [off if o in (-1, me) else 0 for o, off in dig_items]
+        vals = be.gather(self.layers, voff, 1)
+        digs = be.gather(self.trees, doff, 8)
+        nv, nd = len(voff), len(doff)
+        if G > 1:
+            import torch
+            mine = torch.cat([vals, digs])
+            allc = be.empty(mine.numel() * G)
+            self.comm.all_gather(mine, allc)
+            allh = be.to_host(allc).reshape(G, nv + 8 * nd)
+        else:
+            allh = np.concatenate([be.to_host(vals), be.to_host(digs)]).reshape(1, nv + 8 * nd)
+        V = [int(allh[me if o == -1 else o, k]) for k, (o, _) in enumerate(val_items)]
+        D = [words_to_bytes(allh[me if o == -1 else o, nv + 8 * k: nv + 8 * k + 8]) for k, (o, _) in enumerate(dig_items)]
+        dpos = 0
+        paths = []
+        for nloc, top_path in openings:
+            paths.append(D[dpos:dpos + nloc] + top_path)
+            dpos += nloc
+        for k in range(4):
+            ch.commit((V[k], paths[k]))                                               # prover.rs:274-277
+        for i in range(R):
+            ch.commit((V[4 + 2 * i], V[5 + 2 * i], paths[4 + 2 * i], paths[5 + 2 * i]))   # prover.rs:288
+
+    def close(self):
+        self.be.close()
+
+
+def bench(args, rank, local_rank, world, barrier, staged=False):
+    """bench.py leg for N > 1: one proof over `world` GPUs at domain 2^(log_n + log_blowup) * world
+    (weak scaling: per-GPU work equals the single-GPU workload)."""
+    lg = world.bit_length() - 1
+    log_n = args.log_n + lg
+    comm = Comm(staged=staged)
+    be = HipBackend(local_rank)
+    t0 = time.perf_counter()
+    sp = ShardedProver(log_n, args.log_blowup, comm, be)
+    be.sync()
+    setup_ms = (time.perf_counter() - t0) * 1e3
+    trace = trace_fibsq((1 << log_n) - 1)
+    sp.trace_upload(trace)
+    lib = _lib.load()
+
+    def stats():
+        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
+        check(lib.zk_dev_kernel_stats(arr, len(arr), 1))
+        return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes, "ops": a.ops} for name, a in zip(_lib.KERNEL_CLASSES, arr)}
+
+    for _ in range(args.warmup):
+        proof = sp.prove()
+    lib.zk_dev_set_profiling(1 << _lib.KERNEL_CLASSES.index("merkle_leaf"))   # dominant kernel only
+    stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = sp.prove()
+    barrier()
+    dt = time.perf_counter() - t0
+    dom = stats()["merkle_leaf"]
+    if rank == 0:
+        proof.verify()
+    lib.zk_dev_set_profiling((1 << len(_lib.KERNEL_CLASSES)) - 1)
+    sp.prove()
+    per_kernel = stats()
+    lib.zk_dev_set_profiling(0)
+    N = 1 << (log_n + args.log_blowup)
+    res = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": setup_ms, "device_bytes": 0,
+           "proof_bytes": len(proof.data), "scaling": "weak", "units": N * args.steps,
+           "parallelism": f"one proof sharded over {world} GPUs (cyclic domain, all-to-all per commitment)",
+           "log_n": log_n}
+    sp.close()
+    return res
