@@ -328,8 +328,6 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
 
 constexpr int kMerkleThreads = 256;
 constexpr uint32_t kMerkleMaxK = 4;
-constexpr uint32_t kMerkleTopLog = 11;   // the top kernel takes up to 2^11 inputs
-constexpr int kTopThreads = 1024;
 
 __device__ __forceinline__ void store_digest(uint32_t* nodes, size_t node, const Digest& d) {
     uint4* q = reinterpret_cast<uint4*>(nodes + node * 8);
@@ -383,53 +381,63 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const ui
     }
 }
 
-// Finishes a tree whose level `depth_in` has <= 2^11 nodes: one workgroup, level kept in LDS.
+// Latency-bound part of a tree.  A level with <= 65 536 nodes costs one hash latency however it
+// is scheduled (one wave per SIMD already issues a VALU op every 4 cycles), so what matters here
+// is the number of grid-wide synchronisations.  Each workgroup takes 2^j consecutive nodes of
+// level `depth_in` (raw values in LEAF mode), keeps them in LDS and reduces them to ONE node with
+// workgroup barriers only; a launch therefore lowers the tree by j levels.
+constexpr int kWgThreads = 256;
+constexpr uint32_t kWgMaxLog = 10;   // 1024 digests = 32 KiB LDS per workgroup
+
+__device__ __forceinline__ Digest lds_digest(const uint4* p) {
+    uint4 lo = p[0], hi = p[1];
+    Digest d;
+    d.w[0] = lo.x; d.w[1] = lo.y; d.w[2] = lo.z; d.w[3] = lo.w;
+    d.w[4] = hi.x; d.w[5] = hi.y; d.w[6] = hi.z; d.w[7] = hi.w;
+    return d;
+}
+__device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
+    p[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+    p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+}
+
 template <bool LEAF>
-__global__ __launch_bounds__(kTopThreads) void merkle_top_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in) {
-    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^depth_in][2]
+__global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in, uint32_t j) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2]
     const uint32_t tid = threadIdx.x;
-    const uint32_t cnt = 1u << depth_in;
+    const uint32_t cnt = 1u << j;
+    const size_t first = (size_t)blockIdx.x << j;                 // first input of this workgroup
     const size_t in_base = ((size_t)1 << depth_in) - 1;
-    for (uint32_t i = tid; i < cnt; i += kTopThreads) {
+#pragma unroll 1
+    for (uint32_t i = tid; i < cnt; i += kWgThreads) {
         Digest d;
         if (LEAF) {
-            d = sha256_leaf(vals[i]);
-            store_digest(nodes, in_base + i, d);
+            d = sha256_leaf(vals[first + i]);
+            store_digest(nodes, in_base + first + i, d);
         } else {
-            d = load_digest(nodes, in_base + i);
+            d = load_digest(nodes, in_base + first + i);
         }
-        lvl[2 * i] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
-        lvl[2 * i + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+        lds_store(&lvl[2 * i], d);
     }
     __syncthreads();
 #pragma unroll 1
-    for (int dd = (int)depth_in - 1; dd >= 0; --dd) {
-        const uint32_t w = 1u << dd;
-        // w <= 1024 = kTopThreads: at most one node per thread per level
-        Digest d;
-        const bool active = tid < w;
-        if (active) {
-            uint4 a0 = lvl[4 * tid], a1 = lvl[4 * tid + 1], b0 = lvl[4 * tid + 2], b1 = lvl[4 * tid + 3];
-            Digest l, r;
-            l.w[0] = a0.x; l.w[1] = a0.y; l.w[2] = a0.z; l.w[3] = a0.w;
-            l.w[4] = a1.x; l.w[5] = a1.y; l.w[6] = a1.z; l.w[7] = a1.w;
-            r.w[0] = b0.x; r.w[1] = b0.y; r.w[2] = b0.z; r.w[3] = b0.w;
-            r.w[4] = b1.x; r.w[5] = b1.y; r.w[6] = b1.z; r.w[7] = b1.w;
-            d = sha256_inner(l, r);
-            store_digest(nodes, (((size_t)1 << dd) - 1) + tid, d);
-        }
+    for (uint32_t t = 1; t <= j; ++t) {
+        const uint32_t w = cnt >> t;                              // nodes of this level in the workgroup
+        const size_t out_base = (((size_t)1 << (depth_in - t)) - 1) + (first >> t);
+        // in place: node u is written over child slot u after every thread of the level has read
+        Digest d0, d1;
+        const bool a0 = tid < w, a1 = tid + kWgThreads < w;       // w <= 512: at most two nodes per thread
+        if (a0) d0 = sha256_inner(lds_digest(&lvl[4 * tid]), lds_digest(&lvl[4 * tid + 2]));
+        if (a1) d1 = sha256_inner(lds_digest(&lvl[4 * (tid + kWgThreads)]), lds_digest(&lvl[4 * (tid + kWgThreads) + 2]));
         __syncthreads();
-        if (active) {
-            lvl[2 * tid] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
-            lvl[2 * tid + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
-        }
+        if (a0) { lds_store(&lvl[2 * tid], d0); store_digest(nodes, out_base + tid, d0); }
+        if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
         __syncthreads();
     }
 }
 
-// Algorithmic bytes of a launch that takes 2^depth inputs down k levels: inputs read once
-// (4 B values or 32 B digests), every produced digest written once.
 static double merkle_bytes(bool leaf, uint32_t depth, uint32_t k) {
+    // inputs read once (4 B values or 32 B digests), every produced digest written once
     double in = (double)((size_t)1 << depth);
     double produced = (leaf ? in : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k));
     return (leaf ? 4.0 : 32.0) * in + 32.0 * produced;
@@ -439,20 +447,17 @@ static double merkle_ops(bool leaf, uint32_t depth, uint32_t k) {
     return (leaf ? in * kShaLeafOps : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k)) * kShaInnerOps;
 }
 
+// Throughput phase: subtree launches (k <= 4 levels each) while the level has more than 2^18 nodes,
+// i.e. while there are more than ~4 waves per SIMD to keep busy.  Latency phase: workgroup launches
+// of up to 10 levels each.
+constexpr uint32_t kMerkleLatencyLog = 18;
+
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof) {
     uint32_t depth = log_m;
-    if (depth <= kMerkleTopLog) {
-        size_t sh = ((size_t)2 << depth) * sizeof(uint4);
-        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(true, depth, depth), s, merkle_ops(true, depth, depth));
-        hipLaunchKernelGGL(merkle_top_kernel<true>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
-        return hipGetLastError();
-    }
     bool leaf = true;
-    while (depth > kMerkleTopLog) {
-        // keep >= 2^18 lanes in flight (256 CUs x 4 SIMDs x 64 lanes x 4 waves) while they last
-        uint32_t k = depth > 18 ? depth - 18 : 1;
+    while (depth > kMerkleLatencyLog) {
+        uint32_t k = depth - kMerkleLatencyLog;
         if (k > kMerkleMaxK) k = kMerkleMaxK;
-        if (depth - k < kMerkleTopLog) k = depth - kMerkleTopLog;
         size_t lanes = (size_t)1 << (depth - k);
         uint32_t blocks = (uint32_t)((lanes + kMerkleThreads - 1) / kMerkleThreads);
         size_t sh = (size_t)k * 2 * kMerkleThreads * sizeof(uint4);
@@ -462,9 +467,19 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         leaf = false;
         depth -= k;
     }
-    size_t sh = ((size_t)2 << depth) * sizeof(uint4);
-    ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(false, depth, depth), s, merkle_ops(false, depth, depth));
-    hipLaunchKernelGGL(merkle_top_kernel<false>, dim3(1), dim3(kTopThreads), sh, s, vals, nodes, depth);
+    do {
+        // split the remaining levels evenly over the launches (each <= kWgMaxLog)
+        uint32_t launches = (depth + kWgMaxLog - 1) / kWgMaxLog;
+        if (launches == 0) launches = 1;
+        uint32_t j = (depth + launches - 1) / launches;
+        uint32_t blocks = 1u << (depth - j);
+        size_t sh = ((size_t)2 << j) * sizeof(uint4);
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(leaf, depth, j), s, merkle_ops(leaf, depth, j));
+        if (leaf) hipLaunchKernelGGL(merkle_wg_kernel<true>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j);
+        else hipLaunchKernelGGL(merkle_wg_kernel<false>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j);
+        leaf = false;
+        depth -= j;
+    } while (depth > 0);
     return hipGetLastError();
 }
 
