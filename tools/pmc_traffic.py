@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as gpurun requires)
+into profiles/traffic.json: HBM bytes per launch of each kernel.
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read, so it is
+doubled (checked here on ntt_pass_kernel<1>, which reads 4 * 2^24 B and reports 32 MiB);
+WRITE_SIZE is exact for streaming stores.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 profiles/traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    F, W = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --steps 1 --warmup 1`; "
+                      "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over all launches of the kernel", "kernels": {}}
+    for k in sorted(set(F) | set(W)):
+        if not k.startswith(("void zk::", "zk::")):
+            continue
+        nf, nw = len(F.get(k, [])), len(W.get(k, []))
+        fb = 2.0 * sum(F.get(k, [])) * 1024 / max(nf, 1)
+        wb = sum(W.get(k, [])) * 1024 / max(nw, 1)
+        res["kernels"][k] = {"launches_seen": nf, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                             "hbm_bytes_per_launch": fb + wb}
+    leaf = [v for k, v in res["kernels"].items() if "merkle_subtree_kernel<true>" in k]
+    if leaf:
+        res["merkle_leaf_bytes_per_launch"] = leaf[0]["hbm_bytes_per_launch"]
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res["kernels"].items():
+        print(f"{v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  {k[:90]}")
+
+
+if __name__ == "__main__":
+    main()

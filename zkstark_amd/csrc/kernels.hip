@@ -320,10 +320,12 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
 // Heap layout of merkle.rs:14-51: 2m-1 nodes, root 0, children of j at 2j+1, 2j+2,
 // depth d occupies [2^d - 1, 2^(d+1) - 1), leaf i at m - 1 + i.
 //
-// SHA-256 is integer-VALU bound, so the design goal is 100 % lane utilisation and no
-// cross-lane traffic: a lane owns 2^k consecutive inputs and reduces that subtree
-// depth-first entirely in its own registers, with a k-entry digest stack in LDS.
-// All control flow is wave-uniform.  One launch lowers the tree by k levels; the last
+// SHA-256 is integer-VALU bound, so the design goal is 100 % lane utilisation with every
+// HBM access a full line.  A wave owns 64 * 2^k consecutive inputs and walks them in groups of
+// 64: group i is hashed by the 64 lanes (one coalesced 256 B / 2 KiB access), two sibling groups
+// are paired through a 4 KiB LDS buffer into the 64 parents (lane j hashes children 2j, 2j+1), and
+// so on up k levels like a binary counter -- every level keeps all 64 lanes busy and every
+// digest is written once in a contiguous 2 KiB run.  All control flow is wave-uniform.  One launch lowers the tree by k levels; the last
 // <= 2^11 nodes are finished by a single workgroup that keeps the level in LDS.
 
 constexpr int kMerkleThreads = 256;
@@ -343,40 +345,50 @@ __device__ __forceinline__ Digest load_digest(const uint32_t* nodes, size_t node
     return d;
 }
 
+__device__ __forceinline__ Digest lds_digest(const uint4* p) {
+    uint4 lo = p[0], hi = p[1];
+    Digest d;
+    d.w[0] = lo.x; d.w[1] = lo.y; d.w[2] = lo.z; d.w[3] = lo.w;
+    d.w[4] = hi.x; d.w[5] = hi.y; d.w[6] = hi.z; d.w[7] = hi.w;
+    return d;
+}
+
 template <bool LEAF>
 __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const uint32_t* vals, uint32_t* nodes,
                                                                         uint32_t depth_in, uint32_t k) {
-    extern __shared__ __attribute__((aligned(16))) uint4 stack[];   // [k][2][threads]
-    const uint32_t tid = threadIdx.x;
-    const size_t gid = (size_t)blockIdx.x * kMerkleThreads + tid;
-    if (gid >= ((size_t)1 << (depth_in - k))) return;   // no barriers below
-    const size_t base = gid << k;
+    // per wave: k levels x 2 groups x 64 digests x 2 uint4
+    extern __shared__ __attribute__((aligned(16))) uint4 stage[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t gwave = (size_t)blockIdx.x * (kMerkleThreads / 64) + wave;
+    const size_t base = gwave << (6 + k);                        // first input of this wave
     const size_t in_base = ((size_t)1 << depth_in) - 1;
+    uint4* my = stage + (size_t)wave * k * 256;
 #pragma unroll 1
     for (uint32_t i = 0; i < (1u << k); ++i) {
         Digest d;
+        const size_t pos = base + (size_t)i * 64 + lane;         // 64 consecutive inputs: coalesced
         if (LEAF) {
-            d = sha256_leaf(vals[base + i]);
-            store_digest(nodes, in_base + base + i, d);
+            d = sha256_leaf(vals[pos]);
+            store_digest(nodes, in_base + pos, d);
         } else {
-            d = load_digest(nodes, in_base + base + i);
+            d = load_digest(nodes, in_base + pos);
         }
         uint32_t idx = i, lvl = 0;
 #pragma unroll 1
-        while (idx & 1u) {   // wave-uniform: i is the same in every lane
-            uint4 lo = stack[(lvl * 2 + 0) * kMerkleThreads + tid];
-            uint4 hi = stack[(lvl * 2 + 1) * kMerkleThreads + tid];
-            Digest l;
-            l.w[0] = lo.x; l.w[1] = lo.y; l.w[2] = lo.z; l.w[3] = lo.w;
-            l.w[4] = hi.x; l.w[5] = hi.y; l.w[6] = hi.z; l.w[7] = hi.w;
-            d = sha256_inner(l, d);
+        while (lvl < k) {                                        // wave-uniform
+            uint4* grp = my + (lvl * 2 + (idx & 1u)) * 128;
+            grp[2 * lane] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+            grp[2 * lane + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+            if (!(idx & 1u)) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4* x = my + lvl * 256 + 4 * lane;          // children 2*lane, 2*lane+1 of the 128 buffered nodes
+            Digest l = lds_digest(x), r = lds_digest(x + 2);
+            __builtin_amdgcn_wave_barrier();
+            d = sha256_inner(l, r);
             idx >>= 1;
             ++lvl;
-            store_digest(nodes, (((size_t)1 << (depth_in - lvl)) - 1) + ((base + i) >> lvl), d);
-        }
-        if (lvl < k) {
-            stack[(lvl * 2 + 0) * kMerkleThreads + tid] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
-            stack[(lvl * 2 + 1) * kMerkleThreads + tid] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+            store_digest(nodes, (((size_t)1 << (depth_in - lvl)) - 1) + (base >> lvl) + (size_t)idx * 64 + lane, d);
         }
     }
 }
@@ -389,13 +401,6 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const ui
 constexpr int kWgThreads = 256;
 constexpr uint32_t kWgMaxLog = 10;   // 1024 digests = 32 KiB LDS per workgroup
 
-__device__ __forceinline__ Digest lds_digest(const uint4* p) {
-    uint4 lo = p[0], hi = p[1];
-    Digest d;
-    d.w[0] = lo.x; d.w[1] = lo.y; d.w[2] = lo.z; d.w[3] = lo.w;
-    d.w[4] = hi.x; d.w[5] = hi.y; d.w[6] = hi.z; d.w[7] = hi.w;
-    return d;
-}
 __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
     p[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
     p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
@@ -458,9 +463,9 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
     while (depth > kMerkleLatencyLog) {
         uint32_t k = depth - kMerkleLatencyLog;
         if (k > kMerkleMaxK) k = kMerkleMaxK;
-        size_t lanes = (size_t)1 << (depth - k);
-        uint32_t blocks = (uint32_t)((lanes + kMerkleThreads - 1) / kMerkleThreads);
-        size_t sh = (size_t)k * 2 * kMerkleThreads * sizeof(uint4);
+        size_t lanes = (size_t)1 << (depth - k);                // >= 2^18: a multiple of the block size
+        uint32_t blocks = (uint32_t)(lanes / kMerkleThreads);
+        size_t sh = (size_t)(kMerkleThreads / 64) * k * 256 * sizeof(uint4);
         ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s, merkle_ops(leaf, depth, k));
         if (leaf) hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
         else hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
