@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--log-n", type=int, default=21, help="log2 of the trace group size n")
     ap.add_argument("--log-blowup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=3, help="also report throughput with this many proofs in flight (1 = skip)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20, help="oracle sample: domain 2^(this+blowup)")
     return ap.parse_args()
 
@@ -131,6 +132,28 @@ def main():
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": ctx.setup_ms,
                   "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
                   "units": N * args.steps, "parallelism": "single-gpu"}
+        if args.in_flight > 1:
+            # secondary figure: several independent proofs in flight on one GPU (one context, stream and
+            # host thread each), so one proof's latency-bound tree tops overlap another's hashing
+            import threading
+            ctxs = [ctx] + [zk.Context(log_n, log_b, device=local_rank) for _ in range(args.in_flight - 1)]
+            for c in ctxs[1:]:
+                c.trace_upload(trace)
+                c.prove()
+            def work(c):
+                for _ in range(args.steps):
+                    c.prove()
+            barrier()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            barrier()
+            dtp = time.perf_counter() - t0
+            result["pipelined"] = {"proofs_in_flight": args.in_flight, "value": args.in_flight * N * args.steps / dtp,
+                                   "unit": "field-elements/s", "ms_per_proof": dtp / (args.in_flight * args.steps) * 1e3}
+            for c in ctxs[1:]:
+                c.close()
         ctx.close()
 
     dt = result["dt"]
@@ -184,6 +207,8 @@ def main():
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],
             "proof_bytes": result["proof_bytes"],
         }
+        if "pipelined" in result:
+            out["pipelined"] = result["pipelined"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
         print(json.dumps(out), flush=True)

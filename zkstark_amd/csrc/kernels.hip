@@ -406,8 +406,12 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
     p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
 }
 
+// When the launch produces the root (depth_in == j) and a mailbox is given, the root is also
+// written to host-mapped memory followed by a sequence number, so the host prover can poll for
+// it instead of paying a blit kernel + stream synchronisation per commitment.
 template <bool LEAF>
-__global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in, uint32_t j) {
+__global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in, uint32_t j,
+                                                               uint32_t* mailbox, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2]
     const uint32_t tid = threadIdx.x;
     const uint32_t cnt = 1u << j;
@@ -439,6 +443,12 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* v
         if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
         __syncthreads();
     }
+    if (mailbox && depth_in == j && tid == 0) {
+        Digest r = lds_digest(&lvl[0]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __hip_atomic_store(&mailbox[2 + i], r.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 static double merkle_bytes(bool leaf, uint32_t depth, uint32_t k) {
@@ -457,7 +467,8 @@ static double merkle_ops(bool leaf, uint32_t depth, uint32_t k) {
 // of up to 10 levels each.
 constexpr uint32_t kMerkleLatencyLog = 18;
 
-hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof) {
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                               uint32_t* mailbox, uint32_t seq) {
     uint32_t depth = log_m;
     bool leaf = true;
     while (depth > kMerkleLatencyLog) {
@@ -480,8 +491,8 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         uint32_t blocks = 1u << (depth - j);
         size_t sh = ((size_t)2 << j) * sizeof(uint4);
         ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(leaf, depth, j), s, merkle_ops(leaf, depth, j));
-        if (leaf) hipLaunchKernelGGL(merkle_wg_kernel<true>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j);
-        else hipLaunchKernelGGL(merkle_wg_kernel<false>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j);
+        if (leaf) hipLaunchKernelGGL(merkle_wg_kernel<true>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+        else hipLaunchKernelGGL(merkle_wg_kernel<false>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
         leaf = false;
         depth -= j;
     } while (depth > 0);

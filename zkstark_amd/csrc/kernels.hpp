@@ -127,7 +127,9 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof = nu
 
 // Merkle tree over m = 2^log_m u32 leaves.  nodes: (2m-1) * 8 words, heap order
 // (merkle.rs:14-51), each node the eight SHA-256 state words.
-hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr);
+// mailbox (optional): 10 words of host-mapped memory; word 0 <- seq after words 2..9 <- root state words.
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
+                               uint32_t* mailbox = nullptr, uint32_t seq = 0);
 
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,

@@ -286,6 +286,9 @@ struct zk_ctx {
     uint64_t* h_gather_off = nullptr;   // pinned
     uint32_t* h_gather_out = nullptr;   // pinned
     uint32_t* h_small = nullptr;        // pinned: root words + last layer
+    uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: [seq, -, root words 0..7]
+    uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
+    uint32_t mail_seq = 0;
     size_t gather_cap = 0;
     size_t device_bytes = 0;
     double setup_ms = 0;
@@ -334,9 +337,32 @@ int do_lde(zk_ctx* c) {
     return rc;
 }
 
+// Builds tree `layer`; the launch that produces the root also posts it to the host mailbox.
 int do_merkle(zk_ctx* c, uint32_t layer) {
+    c->mail_seq += 1;
     HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer),
-                               c->d_trees + c->tree_off[layer], c->stream, prof_of(c)));
+                               c->d_trees + c->tree_off[layer], c->stream, prof_of(c), c->d_mailbox, c->mail_seq));
+    return ZK_OK;
+}
+
+// Waits for the root posted by the last do_merkle (polling host-coherent memory: no blit kernel, no
+// stream synchronisation on the commit -> challenge critical path).
+int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
+    (void)tree;
+    const uint32_t want = c->mail_seq;
+    auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (__atomic_load_n(&c->h_mailbox[0], __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 0xFFFF) == 0) {
+            if (hipStreamQuery(c->stream) == hipSuccess && __atomic_load_n(&c->h_mailbox[0], __ATOMIC_ACQUIRE) != want)
+                return fail(ZK_ERR_HIP, "merkle root was never posted (stream drained)");
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+                return fail(ZK_ERR_HIP, "timed out waiting for a merkle root");
+        }
+    }
+    uint32_t w[8];
+    for (int i = 0; i < 8; ++i) w[i] = __atomic_load_n(&c->h_mailbox[2 + i], __ATOMIC_RELAXED);
+    digest_words_to_bytes(w, out);
     return ZK_OK;
 }
 
@@ -348,13 +374,6 @@ int do_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
 int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
     return dom_fold(c->dom, c->d_layers + c->layer_off[1 + round], c->d_layers + c->layer_off[2 + round],
                     c->L - round, round, beta_raw, c->stream, prof_of(c));
-}
-
-int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
-    HIPCHK(hipMemcpyAsync(c->h_small, c->d_trees + c->tree_off[tree], 32, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    digest_words_to_bytes(c->h_small, out);
-    return ZK_OK;
 }
 
 // merkle.rs:54-71: node indices of the authentication path of `leaf` in a tree of m leaves
@@ -526,6 +545,9 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8));
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_out, c->gather_cap * 32));
     HIPCHK_C(hipHostMalloc((void**)&c->h_small, 4096));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_mailbox, 0, 64);
+    HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_mailbox, 0));
 #undef HIPCHK_C
     c->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = c;
@@ -546,6 +568,7 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (c->h_gather_off) (void)hipHostFree(c->h_gather_off);
     if (c->h_gather_out) (void)hipHostFree(c->h_gather_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_mailbox) (void)hipHostFree(c->h_mailbox);
     collect_kernel_stats(c);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
