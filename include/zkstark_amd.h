@@ -189,7 +189,7 @@ typedef struct zk_dom zk_dom;
 int zk_dom_create(int device, uint32_t log_n, uint32_t log_blowup, uint32_t shift, int fold_only, zk_dom **out);
 int zk_dom_destroy(zk_dom *dom);
 /* lagrange + solve (polynomial.rs:337, :49; prover.rs:60-70).  d_trace: n words = a[0..n-2] followed
- * by 0; d_coef: n words scratch; d_out: N words, natural order. */
+ * by 0; d_coef: 2n words scratch; d_out: N words, natural order. */
 int zk_dev_lde(const zk_dom *dom, const uint32_t *d_trace, uint32_t *d_coef, uint32_t *d_out, void *stream);
 /* prover.rs:101-173 pointwise; first = a[0], last = a[n-2]. */
 int zk_dev_compose(const zk_dom *dom, const uint32_t *d_f, uint32_t *d_cp, uint32_t first, uint32_t last,

@@ -85,7 +85,7 @@ def test_shard_domain_primitives_match_definition(zk, orc, log_n, log_b, rank_ex
     tr0 = np.concatenate([trace, np.zeros(1, dtype=np.uint32)])
     th, to = hb.upload(tr0), ob.upload(tr0)
     fh, fo = hb.empty(N), ob.empty(N)
-    hb.lde(dh, th, hb.empty(n), fh)
+    hb.lde(dh, th, hb.empty(2 * n), fh)
     ob.lde(do, to, ob.empty(n), fo)
     assert np.array_equal(hb.to_host(fh), ob.to_host(fo))
     alphas = [int(rng.integers(0, 2**32)) for _ in range(3)]

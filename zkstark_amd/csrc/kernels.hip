@@ -79,25 +79,13 @@ __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(NttPassArgs p) {
 
     // ---- load ---------------------------------------------------------------
     if (MODE == NTT_DIT_LDE) {
-        // S = B.  Each coefficient feeds B columns: the innermost radix-B stage of the
-        // size-N transform sees (c, 0, ..., 0) and is a replication.  The coefficient is
-        // first corrected for the virtual last trace point (DESIGN.md "LDE"), then scaled
-        // by w^k / n (coset shift, prover.rs:69, and the iNTT normalisation).
-        const uint32_t logB = logS, n = 1u << p.log_n;
-        const uint32_t c_top = p.src[n - 1u];
+        // S = B.  Each (prepared) coefficient feeds B columns: the innermost radix-B stage of the
+        // size-N transform sees (c, 0, ..., 0) and is a replication.
+        const uint32_t logB = logS;
         const uint32_t a0 = col0 >> logB;
         for (uint32_t u = tid; u < (tile_elems >> logB); u += kNttThreads) {
             uint32_t ao = u >> logR, t = u & (R - 1u);
-            uint32_t pos = ((a0 + ao) << logR) | t;
-            uint32_t k = 0, rem = p.log_n, sh = 0;
-            for (uint32_t d = 0; d < p.nd; ++d) {
-                rem -= p.dig_bits[d];
-                k |= ((pos >> rem) & ((1u << p.dig_bits[d]) - 1u)) << sh;
-                sh += p.dig_bits[d];
-            }
-            uint32_t v = p.src[pos];
-            v = sub(v, mont_mul(c_top, pow_lookup(p.tw, ((k + 1u) & (n - 1u)) << logB)));
-            v = mont_mul(v, mont_mul(pow_lookup(p.wtab, k), p.ninv_mont));
+            uint32_t v = p.src[((size_t)(a0 + ao) << logR) | t];
             uint32_t row = __brev(t) >> (32u - logR);
             uint32_t* dstp = &tile[row * pitch + (ao << logB)];
             dstp[0] = v;
@@ -170,11 +158,15 @@ __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(NttPassArgs p) {
     }
 }
 
+bool launch_ntt_pass_fast(const NttPassArgs& a, NttMode mode, hipStream_t s, hipError_t* err);   // ntt_fast.hip
+
 hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Profiler* prof) {
     // algorithmic bytes: every element read once and written once (the LDE pass reads n, writes N)
-    double bytes = mode == NTT_DIT_LDE ? 4.0 * ((double)(1u << a.log_n) + (double)((size_t)1 << a.log_total))
+    double bytes = mode == NTT_DIT_LDE ? 4.0 * ((double)((size_t)1 << (a.log_total - a.logS)) + (double)((size_t)1 << a.log_total))
                                        : 8.0 * (double)((size_t)1 << a.log_total);
     ScopedKernelTimer tm(prof, K_NTT, bytes, s);
+    hipError_t ferr = hipSuccess;
+    if (launch_ntt_pass_fast(a, mode, s, &ferr)) return ferr;
     uint32_t cols_log = a.log_total - a.logR;
     uint32_t blocks = 1u << (cols_log - a.logC);
     size_t shmem = ((size_t)(1u << a.logR) * ((1u << a.logC) + 1u) + (1u << a.logR) / 2u) * sizeof(uint32_t);
@@ -183,6 +175,31 @@ hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Pr
         case NTT_DIT: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
         case NTT_DIT_LDE: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT_LDE>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
     }
+    return hipGetLastError();
+}
+
+// Interpolant coefficients for the LDE, from the unscaled DIF output U of (a_0..a_{n-2}, 0):
+//   out[pos] = (U[pos] - U[n-1] g^(k+1)) * shift^k / n,   k = true index of storage position pos.
+// The first term removes the degree-(n-1) coefficient (the reference interpolates n-1 points,
+// prover.rs:60: "virtual last trace point"), shift^k moves to the coset (prover.rs:69).
+__global__ __launch_bounds__(256) void coef_prepare_kernel(const uint32_t* U, uint32_t* out, CoefPrepArgs a) {
+    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
+    if (pos >= n) return;
+    uint32_t k = 0, rem = a.log_n, sh = 0;
+    for (uint32_t d = 0; d < a.nd; ++d) {
+        rem -= a.dig_bits[d];
+        k |= ((pos >> rem) & ((1u << a.dig_bits[d]) - 1u)) << sh;
+        sh += a.dig_bits[d];
+    }
+    const uint32_t c_top = U[n - 1u];
+    uint32_t v = sub(U[pos], mont_mul(c_top, pow_lookup(a.tw, ((k + 1u) & (n - 1u)) << a.log_b)));
+    out[pos] = mont_mul(v, mont_mul(pow_lookup(a.wtab, k), a.ninv_mont));
+}
+
+hipError_t launch_coef_prepare(const uint32_t* U, uint32_t* out, const CoefPrepArgs& a, hipStream_t s, Profiler* prof) {
+    uint32_t n = 1u << a.log_n;
+    ScopedKernelTimer tm(prof, K_NTT, 8.0 * n, s);
+    hipLaunchKernelGGL(coef_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, U, out, a);
     return hipGetLastError();
 }
 

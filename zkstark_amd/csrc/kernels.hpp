@@ -68,7 +68,7 @@ constexpr int kMaxDigits = 6;
 enum NttMode : uint32_t {
     NTT_DIF = 0,        // natural in -> digit-reversed out; post-twiddle (inverse-transform passes)
     NTT_DIT = 1,        // digit-reversed in -> natural out; pre-twiddle (forward passes)
-    NTT_DIT_LDE = 2,    // first forward pass of the LDE: reads n scaled coefficients, writes N = n*B values
+    NTT_DIT_LDE = 2,    // first forward pass of the LDE: reads n prepared coefficients, writes N = n*B values
 };
 
 struct NttPassArgs {
@@ -80,13 +80,17 @@ struct NttPassArgs {
     uint32_t L;           // the table root has order 2^L
     PowTable tw;          // h (forward) or h^-1 (inverse)
     uint32_t scale_mont;  // NTT_DIF only: multiply outputs by this Montgomery constant when S == 1 (n^-1); 0 = none
-    // NTT_DIT_LDE only:
-    PowTable wtab;        // powers of the coset shift w
-    uint32_t log_n;       // coefficient count
+};
+
+struct CoefPrepArgs {
+    uint32_t log_n, log_b;
+    PowTable tw;          // h (order 2^(log_n+log_b)): g^j = h^(j << log_b)
+    PowTable wtab;        // powers of the coset shift
     uint32_t ninv_mont;   // n^-1 in Montgomery form
-    uint32_t nd;          // number of storage digits of the coefficient array, slowest first
+    uint32_t nd;          // storage digits of the coefficient array, slowest first
     uint32_t dig_bits[kMaxDigits];
 };
+hipError_t launch_coef_prepare(const uint32_t* U, uint32_t* out, const CoefPrepArgs& a, hipStream_t s, Profiler* prof = nullptr);
 
 hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Profiler* prof = nullptr);
 // out[pos] = in[true_index(pos)] for the mixed-radix digit reversal (standalone NTT API only)

@@ -1,0 +1,246 @@
+// ntt_fast.hip -- register-radix NTT pass for the full-size tiles (R = 64, 128, 256).
+//
+// Same pass semantics as ntt_pass_kernel (kernels.hip): the array is [A][R][S], a workgroup owns
+// C columns x R rows (R*C = 8192 words).  Here the R-point transform is a four-step inside the
+// tile, R = Ra*Rb with Ra, Rb <= 16:
+//
+//   step 1  thread (tb, c): loads rows ta*Rb + tb, ta < Ra, straight into registers (lanes run
+//           along c: one 256 B row segment per wave-instruction), applies the inter-pass twiddle
+//           as a running product, runs the Ra-point DFT in registers with compile-time
+//           twiddles (17 multiplies for 16 points, 5 for 8), multiplies by w_R^(tb*ka) and
+//           writes row ka*Rb + tb of the LDS tile;
+//   step 2  thread (ka, c): reads rows ka*Rb + tb, Rb-point DFT in registers, stores rows
+//           ka + Ra*kb straight to HBM (again whole row segments).
+//
+// One LDS round trip and one barrier per pass instead of log2(R); ~3.8 Montgomery products per
+// element per pass instead of ~9.  Passes whose inner stride S is smaller than C (the innermost
+// pass and the first LDE pass) stage their contiguous tile through LDS so that HBM accesses stay
+// full lines.  No bit reversal anywhere: register naming absorbs it.
+#include "kernels.hpp"
+
+#include "field.hpp"
+
+namespace zk {
+
+namespace {
+
+constexpr uint32_t c_mulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); }
+constexpr uint32_t c_powmod(uint32_t a, uint64_t e) {
+    uint32_t r = 1, b = a;
+    while (e) {
+        if (e & 1) r = c_mulmod(r, b);
+        b = c_mulmod(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+constexpr uint32_t c_to_mont(uint32_t a) { return (uint32_t)((((uint64_t)a) << 32) % P); }
+constexpr uint32_t kW16 = c_powmod(GEN_W, (uint64_t)(P - 1) >> 4);          // primitive 16th root of unity
+constexpr uint32_t kW16Inv = c_powmod(kW16, 15);
+
+// w16^e (forward) or w16^-e (inverse) in Montgomery form, e < 8
+template <bool INV>
+struct Root16 {
+    static constexpr uint32_t w(int e) { return c_to_mont(c_powmod(INV ? kW16Inv : kW16, (uint64_t)e)); }
+};
+
+constexpr int c_brev(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// In-register DFT of 2^LOG points, radix-2 decimation in frequency: natural order in,
+// x[i] = X[bitrev(i)] out.  All indices and twiddles are compile-time constants.
+template <bool INV, int LOG>
+__device__ __forceinline__ void dft_regs(uint32_t (&x)[1 << LOG]) {
+    constexpr int R = 1 << LOG;
+#pragma unroll
+    for (int ll = LOG - 1; ll >= 0; --ll) {
+#pragma unroll
+        for (int b = 0; b < R / 2; ++b) {
+            const int len = 1 << ll;
+            const int j = b & (len - 1);
+            const int i = ((b >> ll) << (ll + 1)) | j;
+            const int e = (j << (LOG - 1 - ll)) * (16 / R);      // exponent of w16
+            uint32_t u = x[i], v = x[i + len];
+            x[i] = add(u, v);
+            uint32_t d = sub(u, v);
+            x[i + len] = (e == 0) ? d : mont_mul(d, Root16<INV>::w(e));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t pow_lookup(const PowTable& t, uint32_t e) {
+    return mont_mul(t.hi[e >> t.lo_bits], t.lo[e & ((1u << t.lo_bits) - 1u)]);
+}
+
+constexpr int kThreads = 256;
+constexpr uint32_t kTileLog = 13;
+
+// MODE: NTT_DIF (inverse passes: DFT with w^-1, post-twiddle), NTT_DIT (forward passes: pre-twiddle),
+//       NTT_DIT_LDE (forward, S = B, source = n prepared coefficients, each feeding B columns).
+// STAGED: the tile is one contiguous block of HBM (S < C): go through LDS for full-line accesses.
+template <uint32_t MODE, int LA, int LB, bool STAGED>
+__global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) {
+    constexpr bool INV = (MODE == NTT_DIF);
+    constexpr int LOGR = LA + LB, R = 1 << LOGR, RA = 1 << LA, RB = 1 << LB;
+    constexpr int LOGC = (int)kTileLog - LOGR, C = 1 << LOGC;
+    constexpr int PITCH = STAGED || MODE == NTT_DIT_LDE ? C + 1 : C;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* tile = smem;                    // R * PITCH
+    uint32_t* twl = smem + R * PITCH;         // w_R^e, e < R
+    const uint32_t tid = threadIdx.x;
+    const uint32_t logS = p.logS;
+    const uint32_t col0 = blockIdx.x << LOGC;
+    const uint32_t smask = (1u << logS) - 1u;
+    const uint32_t tw_shift = p.L - LOGR - logS;
+
+    for (uint32_t e = tid; e < (uint32_t)R; e += kThreads) twl[e] = pow_lookup(p.tw, e << (p.L - LOGR));
+
+    // global word address of (column c of this tile, row t)
+    auto gaddr = [&](uint32_t c, uint32_t t) -> size_t {
+        uint32_t col = col0 + c, a = col >> logS, s = col & smask;
+        return ((size_t)a << (LOGR + logS)) | ((size_t)t << logS) | s;
+    };
+
+    if (STAGED && MODE != NTT_DIT_LDE) {
+        // the tile is R*C consecutive words: copy in memory order, lanes along the fastest index
+        const size_t base = (size_t)blockIdx.x << kTileLog;
+#pragma unroll 4
+        for (uint32_t l = tid; l < (uint32_t)(R * C); l += kThreads) {
+            uint32_t s = l & smask, t = (l >> logS) & (R - 1), c = ((l >> (LOGR + logS)) << logS) | s;
+            tile[t * PITCH + c] = p.src[base + l];
+        }
+    }
+    __syncthreads();   // twl (and the staged tile) visible
+
+    // ---- step 1: Ra-point DFTs over ta (row stride Rb) ---------------------------------
+#pragma unroll 1
+    for (uint32_t q = tid; q < (uint32_t)(RB * C); q += kThreads) {
+        const uint32_t c = q & (C - 1), tb = q >> LOGC;
+        const uint32_t s = (col0 + c) & smask;
+        uint32_t x[RA];
+        if (MODE == NTT_DIT_LDE) {
+            const uint32_t a = (col0 + c) >> logS;                 // coefficient block; B columns share it
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) x[ta] = p.src[((size_t)a << LOGR) | (uint32_t)(ta * RB + tb)];
+        } else if (STAGED) {
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) x[ta] = tile[(ta * RB + tb) * PITCH + c];
+        } else {
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) x[ta] = p.src[gaddr(c, ta * RB + tb)];
+        }
+        if (MODE != NTT_DIF && logS) {
+            // pre-twiddle w_{RS}^(t*s), t = ta*Rb + tb: running product over ta
+            uint32_t cur = pow_lookup(p.tw, (tb * s) << tw_shift);
+            const uint32_t step = pow_lookup(p.tw, ((uint32_t)RB * s) << tw_shift);
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) {
+                x[ta] = mont_mul(x[ta], cur);
+                if (ta + 1 < RA) cur = mont_mul(cur, step);
+            }
+        }
+        // (staged tile: this DFT reads and rewrites only rows = tb (mod Rb) of column c, which no other
+        //  DFT of step 1 touches, so no barrier is needed between its loads and its stores)
+        dft_regs<INV, LA>(x);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int ka = c_brev(i, LA);
+            uint32_t v = x[i];
+            if (ka != 0) v = mont_mul(v, twl[tb * ka]);
+            tile[(ka * RB + tb) * PITCH + c] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- step 2: Rb-point DFTs over tb (consecutive rows) ----------------------------------
+    uint32_t keep[(RA * C) / kThreads][RB];   // staged stores wait until every thread has read the tile
+#pragma unroll
+    for (int it = 0; it < (RA * C) / kThreads; ++it) {
+        const uint32_t q = tid + it * kThreads;
+        const uint32_t c = q & (C - 1), ka = q >> LOGC;
+        const uint32_t s = (col0 + c) & smask;
+        uint32_t (&y)[RB] = keep[it];
+#pragma unroll
+        for (int tb = 0; tb < RB; ++tb) y[tb] = tile[(ka * RB + tb) * PITCH + c];
+        dft_regs<INV, LB>(y);
+        if (MODE == NTT_DIF) {
+            if (logS) {
+                // post-twiddle w_{RS}^(k*s), k = ka + Ra*kb: running product over kb
+                uint32_t cur = pow_lookup(p.tw, (ka * s) << tw_shift);
+                const uint32_t step = pow_lookup(p.tw, ((uint32_t)RA * s) << tw_shift);
+#pragma unroll
+                for (int kb = 0; kb < RB; ++kb) {
+                    const int i = c_brev(kb, LB);
+                    y[i] = mont_mul(y[i], cur);
+                    if (kb + 1 < RB) cur = mont_mul(cur, step);
+                }
+            } else if (p.scale_mont) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) y[i] = mont_mul(y[i], p.scale_mont);
+            }
+        }
+        if (!STAGED) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) p.dst[gaddr(c, ka + RA * c_brev(i, LB))] = y[i];
+        }
+    }
+    if (STAGED) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (RA * C) / kThreads; ++it) {
+            const uint32_t q = tid + it * kThreads;
+            const uint32_t c = q & (C - 1), ka = q >> LOGC;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) tile[(ka + RA * c_brev(i, LB)) * PITCH + c] = keep[it][i];
+        }
+        __syncthreads();
+        const size_t base = (size_t)blockIdx.x << kTileLog;
+#pragma unroll 4
+        for (uint32_t l = tid; l < (uint32_t)(R * C); l += kThreads) {
+            uint32_t s = l & smask, t = (l >> logS) & (R - 1), c = ((l >> (LOGR + logS)) << logS) | s;
+            p.dst[base + l] = tile[t * PITCH + c];
+        }
+    }
+}
+
+template <uint32_t MODE, int LA, int LB>
+hipError_t launch2(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
+    constexpr int R = 1 << (LA + LB), C = 1 << ((int)kTileLog - LA - LB);
+    size_t shmem = ((size_t)R * (C + 1) + R) * sizeof(uint32_t);
+    if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true>), dim3(blocks), dim3(kThreads), shmem, s, a);
+    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false>), dim3(blocks), dim3(kThreads), shmem, s, a);
+    return hipGetLastError();
+}
+
+template <uint32_t MODE>
+hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
+    switch (a.logR) {
+        case 6: return launch2<MODE, 3, 3>(a, staged, blocks, s);
+        case 7: return launch2<MODE, 4, 3>(a, staged, blocks, s);
+        case 8: return launch2<MODE, 4, 4>(a, staged, blocks, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// Returns true if this pass was launched on the fast path (full 8192-word tiles only).
+bool launch_ntt_pass_fast(const NttPassArgs& a, NttMode mode, hipStream_t s, hipError_t* err) {
+    if (a.logR < 6 || a.logR > 8) return false;
+    const uint32_t logC = kTileLog - a.logR;
+    if (a.log_total < kTileLog || a.logC != logC) return false;
+    const bool staged = a.logS < logC;
+    if (mode == NTT_DIT_LDE && !staged) return false;
+    const uint32_t blocks = 1u << (a.log_total - kTileLog);
+    switch (mode) {
+        case NTT_DIF: *err = launch1<NTT_DIF>(a, staged, blocks, s); break;
+        case NTT_DIT: *err = launch1<NTT_DIT>(a, staged, blocks, s); break;
+        case NTT_DIT_LDE: *err = launch1<NTT_DIT_LDE>(a, true, blocks, s); break;
+    }
+    return true;
+}
+
+}  // namespace zk

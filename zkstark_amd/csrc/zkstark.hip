@@ -196,12 +196,22 @@ int dom_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool fo
 }
 
 // lagrange + solve over the coset (polynomial.rs:337, :49; prover.rs:60-70).
-// d_trace: n words (a[0..n-2], 0); d_coef: n words scratch; d_out: N words.
+// d_trace: n words (a[0..n-2], 0); d_coef: 2n words scratch; d_out: N words.
 int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t* d_out, hipStream_t s, Profiler* prof) {
     // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
     int rc = run_dif(d_trace, d_coef, d->log_n, d->plan, d->Hinv.view(), d->L, 0, s, prof);
     if (rc) return rc;
-    // size-N forward transform of the zero-padded, shift^k-scaled coefficients
+    // virtual-point correction, coset shift and 1/n: d_coef[0..n) -> d_coef[n..2n)
+    uint32_t* d_prep = d_coef + d->n;
+    {
+        CoefPrepArgs pa{};
+        pa.log_n = d->log_n; pa.log_b = d->log_b;
+        pa.tw = d->H.view(); pa.wtab = d->W.view(); pa.ninv_mont = d->ninv_mont;
+        pa.nd = d->plan.nd;
+        for (uint32_t t = 0; t < d->plan.nd; ++t) pa.dig_bits[t] = d->plan.bits[t];
+        HIPCHK(launch_coef_prepare(d_coef, d_prep, pa, s, prof));
+    }
+    // size-N forward transform of the zero-padded coefficients
     uint32_t inner = d->log_b;
     for (int q = (int)d->plan.nd - 1; q >= 0; --q) {
         NttPassArgs a{};
@@ -210,10 +220,7 @@ int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t
         a.dst = d_out;
         if (q == (int)d->plan.nd - 1) {
             if (a.logC < d->log_b) a.logC = d->log_b;
-            a.src = d_coef;
-            a.wtab = d->W.view(); a.log_n = d->log_n; a.ninv_mont = d->ninv_mont;
-            a.nd = d->plan.nd;
-            for (uint32_t t = 0; t < d->plan.nd; ++t) a.dig_bits[t] = d->plan.bits[t];
+            a.src = d_prep;
             HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, s, prof));
         } else {
             a.src = d_out;
@@ -276,7 +283,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     zk_dom* dom = nullptr;
     uint32_t* d_trace = nullptr;    // n words: a[0..n-2], 0   (stays resident across proofs)
-    uint32_t* d_coef = nullptr;     // n words: interpolant coefficients, digit-reversed order
+    uint32_t* d_coef = nullptr;     // 2n words: iNTT output, then prepared coefficients (digit-reversed order)
     uint32_t* d_layers = nullptr;   // layer 0 (N) | layer 1 (N) | layer 2 (N/2) | ... | layer R+1 (B)
     std::vector<size_t> layer_off, layer_len;
     uint32_t* d_trees = nullptr;    // tree t over layer t, (2m-1)*8 words each
@@ -536,7 +543,7 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     }
     size_t tree_words = off;
     if ((rc = dmalloc(c, &c->d_trace, c->n * 4))) return bail(rc);
-    if ((rc = dmalloc(c, &c->d_coef, c->n * 4))) return bail(rc);
+    if ((rc = dmalloc(c, &c->d_coef, 2 * c->n * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_layers, layer_words * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_trees, tree_words * 4))) return bail(rc);
     c->gather_cap = (size_t)(4 + 2 * c->R) * (c->L + 1) + 64;

@@ -208,7 +208,7 @@ class ShardedProver:
             off += (2 * self._tree_leaves(t) - 1) * 8
         self.trees = be.empty(off)
         self.trace = be.empty(self.n)
-        self.coef = be.empty(self.n)
+        self.coef = be.empty(2 * self.n)
         self.recv = be.empty(NL)
         self.block = be.empty(NL)
         self.subroot_all = be.empty(8 * G)
