@@ -148,6 +148,11 @@ int zk_kernel_stats(zk_ctx *ctx, zk_kernel_stat *out, size_t count, int reset);
  * (1024, 8192, 10, 2338775057) to (log_n, log_blowup, public_last). */
 int zk_verify(const uint8_t *proof, size_t len, uint32_t log_n, uint32_t log_blowup,
               uint32_t public_last);
+/* zk_verify plus a replay of the Fiat-Shamir channel over the proof bytes: every challenge must be
+ * the one the transcript yields at that point and `state` (Proof.state, proof.rs:6, which the
+ * reference stores but never checks) must be the final channel state.  SURVEY.md section 8f item 1. */
+int zk_verify_strict(const uint8_t *proof, size_t len, const uint8_t state[32], uint32_t log_n,
+                     uint32_t log_blowup, uint32_t public_last);
 /* Proof::size (proof.rs:151-154). */
 size_t zk_proof_size(size_t data_len);
 size_t zk_proof_data_len(uint32_t log_n, uint32_t log_blowup);

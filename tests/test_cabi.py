@@ -133,3 +133,20 @@ def test_context_argument_checks(zk):
         with pytest.raises(zk.ZkError) as e:
             zk.Context(log_n, log_b)
         assert e.value.code == -1
+
+
+def test_strict_verifier_replays_the_transcript(zk, orc):
+    """challenges must be the transcript's, Proof.state must be the final state."""
+    import struct as st
+    r = orc.prove(6, 2, want_vectors=False)
+    good = zk.Proof(r.state, r.proof, 6, 2, r.public_last)
+    good.verify(strict=True)
+    with pytest.raises(zk.ZkError):                      # wrong final state: the lax verifier does not notice
+        zk.Proof(bytes(32), r.proof, 6, 2, r.public_last).verify(strict=True)
+    zk.Proof(bytes(32), r.proof, 6, 2, r.public_last).verify()
+    # a prover that picks its own alpha0: the reference verifier trusts it, the strict one does not
+    forged = bytearray(r.proof)
+    forged[32:36] = st.pack("<I", (st.unpack("<I", forged[32:36])[0] + 1) & 0xFFFFFFFF)
+    with pytest.raises(zk.ZkError) as e:
+        zk.Proof(r.state, bytes(forged), 6, 2, r.public_last).verify(strict=True)
+    assert "transcript" in str(e.value)

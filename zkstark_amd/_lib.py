@@ -71,6 +71,7 @@ SYMBOLS = {
     "zk_prove": (_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
     "zk_verify": (_int, [_vp, _sz, _u32, _u32, _u32]),
+    "zk_verify_strict": (_int, [_vp, _sz, _vp, _u32, _u32, _u32]),
     "zk_proof_size": (_sz, [_sz]),
     "zk_proof_data_len": (_sz, [_u32, _u32]),
     "zk_compute_root_from_path": (_int, [_u32, _sz, _vp, _sz, _vp]),

@@ -166,4 +166,41 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
     return 0;
 }
 
+// the reference verifier reads the challenges out of the proof
+// (proof.rs:22-37) and never checks Proof.state (proof.rs:6); the author flags this as unfinished
+// (readme.md:1).  This replays the Fiat-Shamir channel over the proof bytes in the prover's commit
+// order (prover.rs:85, :163-165, :180, :200, :224, :254, :263, :274-277, :288), checks that every
+// challenge equals the one the transcript yields at that point and that the final state matches.
+// Returns 0, or -(1000 + k) for the k-th challenge / -1999 for the state.
+inline int verify_transcript(const uint8_t* data, size_t len, const uint8_t state[32], uint32_t log_n, uint32_t log_b) {
+    if (log_n < 2 || log_b < 1 || log_n + log_b > 30) return -1;
+    const size_t R = log_n, L = log_n + log_b;
+    if (len != proof_data_len(log_n, log_b)) return -1;
+    Channel ch;
+    const uint8_t* p = data;
+    int k = 0;
+    auto commit = [&](size_t n) { ch.commit_bytes(p, n); p += n; };
+    auto challenge = [&]() -> bool {
+        uint32_t expect = ((uint32_t)ch.state[0] << 24) | ((uint32_t)ch.state[1] << 16) | ((uint32_t)ch.state[2] << 8) | ch.state[3];
+        uint32_t got = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        ++k;
+        if (got != expect) return false;
+        commit(4);
+        return true;
+    };
+    commit(32);                                             // f_eval root
+    for (int i = 0; i < 3; ++i) if (!challenge()) return -(1000 + k);
+    commit(32);                                             // cp root
+    for (size_t r = 0; r < R; ++r) {
+        if (!challenge()) return -(1000 + k);               // beta
+        commit(32);                                         // layer root
+    }
+    commit(4);                                              // free term
+    if (!challenge()) return -(1000 + k);                   // query
+    for (int i = 0; i < 4; ++i) commit(4 + 8 + 32 * L);
+    for (size_t i = 0; i < R; ++i) commit(8 + 2 * (8 + 32 * (L - i)));
+    if (memcmp(ch.state, state, 32)) return -1999;
+    return 0;
+}
+
 }  // namespace zk

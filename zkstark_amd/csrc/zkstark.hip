@@ -741,6 +741,13 @@ int zk_verify(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, 
     return ZK_OK;
 }
 
+int zk_verify_strict(const uint8_t* proof, size_t len, const uint8_t state[32], uint32_t log_n, uint32_t log_b, uint32_t public_last) {
+    if (!proof || !state) return fail(ZK_ERR_INVALID, "zk_verify_strict: null argument");
+    int rc = verify_transcript(proof, len, state, log_n, log_b);
+    if (rc) return fail(ZK_ERR_VERIFY, "transcript replay failed at check %d (challenge not derived from the transcript, or final state mismatch)", rc);
+    return zk_verify(proof, len, log_n, log_b, public_last);
+}
+
 size_t zk_proof_size(size_t data_len) { return 48 + data_len; }   // proof.rs:151-154: size_of::<Proof>() = 32 + 16
 size_t zk_proof_data_len(uint32_t log_n, uint32_t log_b) { return proof_data_len(log_n, log_b); }
 

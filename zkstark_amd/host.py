@@ -111,8 +111,14 @@ class Proof:
         self.state, self.data = bytes(state), bytes(data)
         self.log_n, self.log_blowup, self.public_last = log_n, log_blowup, public_last
 
-    def verify(self):                                # proof.rs:15
-        check(_lib.load().zk_verify(self.data, len(self.data), self.log_n, self.log_blowup, self.public_last))
+    def verify(self, strict=False):                  # proof.rs:15
+        """strict=True also replays the channel: challenges must come from the transcript and `state`
+        must be its final state (the reference trusts the proof for both, proof.rs:22-37)."""
+        if strict:
+            check(_lib.load().zk_verify_strict(self.data, len(self.data), self.state, self.log_n, self.log_blowup,
+                                               self.public_last))
+        else:
+            check(_lib.load().zk_verify(self.data, len(self.data), self.log_n, self.log_blowup, self.public_last))
 
     def size(self):                                  # proof.rs:151
         return _lib.load().zk_proof_size(len(self.data))
