@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=21, help="log2 of the trace group size n")
     ap.add_argument("--log-blowup", type=int, default=3)
+    ap.add_argument("--hash", choices=("sha256", "field"), default="sha256",
+                    help="Merkle hash: the reference's SHA-256 (the benchmark), or the field-native hash of configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="also report throughput with this many proofs in flight (1 = skip)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20, help="oracle sample: domain 2^(this+blowup)")
@@ -109,7 +111,7 @@ def main():
         log_n = result["log_n"]
         N = 1 << (log_n + log_b)
     else:
-        ctx = zk.Context(log_n, log_b, device=local_rank)
+        ctx = zk.Context(log_n, log_b, device=local_rank, hash=args.hash)
         trace = zk.trace_fibsq((1 << log_n) - 1)
         ctx.trace_upload(trace)                      # resident before the timed region
         for _ in range(args.warmup):
@@ -136,7 +138,7 @@ def main():
             # secondary figure: several independent proofs in flight on one GPU (one context, stream and
             # host thread each), so one proof's latency-bound tree tops overlap another's hashing
             import threading
-            ctxs = [ctx] + [zk.Context(log_n, log_b, device=local_rank) for _ in range(args.in_flight - 1)]
+            ctxs = [ctx] + [zk.Context(log_n, log_b, device=local_rank, hash=args.hash) for _ in range(args.in_flight - 1)]
             for c in ctxs[1:]:
                 c.trace_upload(trace)
                 c.prove()
@@ -182,7 +184,8 @@ def main():
             "valu": {"achieved": dom["ops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0, "peak": VALU_PEAK_TOPS,
                      "unit": "T lane-ops/s (32-bit)",
                      "frac": (dom["ops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS) if dom["ms"] > 0 else 0.0,
-                     "ops_per_leaf_hash": 1259, "ops_per_inner_hash": 2293},
+                     "ops_per_leaf_hash": 1259 if args.hash == "sha256" else 10200,
+                     "ops_per_inner_hash": 2293 if args.hash == "sha256" else 10300},
         }
         stages = []
         for name, st in result["per_kernel"].items():
@@ -200,7 +203,7 @@ def main():
             "data": "synthetic Fibonacci-square trace (a0=1, a1=3141592), deterministic",
             "config": {"workload": f"full prover: LDE + compose + FRI + Merkle, domain 2^{log_n + log_b} "
                                    f"(trace group 2^{log_n}, blow-up {1 << log_b})" + (f" per proof; {result['parallelism']}" if world > 1 else ""),
-                       "log_n": log_n, "log_blowup": log_b, "domain": N, "fri_rounds": log_n,
+                       "log_n": log_n, "log_blowup": log_b, "domain": N, "fri_rounds": log_n, "merkle_hash": args.hash,
                        "parallelism": result["parallelism"]},
             "roofline": roofline,
             "stages": stages,
@@ -209,7 +212,7 @@ def main():
         }
         if "pipelined" in result:
             out["pipelined"] = result["pipelined"]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.hash == "sha256":
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
         print(json.dumps(out), flush=True)
     if world > 1:

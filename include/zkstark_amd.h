@@ -48,6 +48,12 @@ enum zk_status {
 
 typedef struct zk_ctx zk_ctx;
 
+/* Merkle hash.  SHA-256 is the reference's (merkle.rs:1-2) and the default everywhere.  The
+ * field-native hash (a Poseidon2-style permutation over GF(P), csrc/fieldhash.hpp) is the build's
+ * own definition for BASELINE.json configs[4]; it has no reference counterpart.  The transcript
+ * (channel.rs) always uses SHA-256.  Functions with an _ex suffix take the selector. */
+enum zk_hash_kind { ZK_HASH_SHA256 = 0, ZK_HASH_FIELD = 1 };
+
 const char *zk_last_error(void);
 const char *zk_version(void);
 
@@ -71,6 +77,8 @@ int zk_ctx_destroy(zk_ctx *ctx);
 double zk_ctx_setup_ms(const zk_ctx *ctx);
 size_t zk_ctx_device_bytes(const zk_ctx *ctx);
 int zk_ctx_sync(zk_ctx *ctx);
+/* Selects the Merkle hash of every later zk_merkle_commit / zk_prove* on this context. */
+int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
 /* The HIP stream every stage is enqueued on (hipStream_t). */
 void *zk_ctx_stream(zk_ctx *ctx);
 
@@ -148,6 +156,8 @@ int zk_kernel_stats(zk_ctx *ctx, zk_kernel_stat *out, size_t count, int reset);
  * (1024, 8192, 10, 2338775057) to (log_n, log_blowup, public_last). */
 int zk_verify(const uint8_t *proof, size_t len, uint32_t log_n, uint32_t log_blowup,
               uint32_t public_last);
+int zk_verify_ex(const uint8_t *proof, size_t len, uint32_t log_n, uint32_t log_blowup,
+                 uint32_t public_last, int hash_kind);
 /* zk_verify plus a replay of the Fiat-Shamir channel over the proof bytes: every challenge must be
  * the one the transcript yields at that point and `state` (Proof.state, proof.rs:6, which the
  * reference stores but never checks) must be the final channel state.  SURVEY.md section 8f item 1. */
@@ -159,6 +169,9 @@ size_t zk_proof_data_len(uint32_t log_n, uint32_t log_blowup);
 /* compute_root_from_path (merkle.rs:82-110), CPU. */
 int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t *path, size_t path_len,
                               uint8_t out[32]);
+
+int zk_compute_root_from_path_ex(uint32_t element, size_t index, const uint8_t *path, size_t path_len,
+                                 uint8_t out[32], int hash_kind);
 
 /* ---- Channel (channel.rs:6-37), host only ------------------------------------ */
 typedef struct zk_channel zk_channel;
@@ -178,6 +191,7 @@ int zk_dev_kernel_stats(zk_kernel_stat *out, size_t count, int reset);
 /* ---- stand-alone primitives on host buffers (upload, run on the GPU, download) -- */
 /* Merkle::new(size, data) (merkle.rs:14): nodes_out = (2m-1)*32 bytes, heap order. */
 int zk_merkle_build_host(int device, const uint32_t *vals, size_t m, uint8_t *nodes_out);
+int zk_merkle_build_host_ex(int device, const uint32_t *vals, size_t m, uint8_t *nodes_out, int hash_kind);
 /* Natural-order NTT / inverse NTT of size 2^log_m with the canonical root
  * zk_field_root_of_unity(log_m); in place on the host buffer. */
 int zk_ntt_host(int device, uint32_t *data, uint32_t log_m, int inverse);
@@ -209,6 +223,7 @@ int zk_dev_gather(const uint32_t *d_src, const uint64_t *d_offsets, uint32_t cou
                   uint32_t *d_out, void *stream);
 /* d_vals: m u32 on the device; d_nodes: (2m-1)*8 u32 state words, heap order. */
 int zk_dev_merkle_build(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_nodes, void *stream);
+int zk_dev_merkle_build_ex(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_nodes, void *stream, int hash_kind);
 /* Byte view of nodes stored as state words: out[32] for node `index`. */
 int zk_dev_merkle_node(const uint32_t *d_nodes, size_t index, uint8_t out[32], void *stream);
 

@@ -72,6 +72,8 @@ def lib():
         L.orc_merkle_trace.restype = sz; L.orc_merkle_trace.argtypes = [vp, sz, sz, vp]
         L.orc_compute_root_from_path.restype = None
         L.orc_compute_root_from_path.argtypes = [u32, sz, vp, sz, vp]
+        L.orc_set_hash.restype = None; L.orc_set_hash.argtypes = [C.c_int]
+        L.orc_fieldhash_permute.restype = None; L.orc_fieldhash_permute.argtypes = [vp]
         L.orc_prove.restype = C.c_int
         L.orc_prove.argtypes = [u32, u32, u32, u32, C.c_int, vp, sz, C.POINTER(sz), vp, C.POINTER(_Debug)]
         L.orc_verify.restype = C.c_int; L.orc_verify.argtypes = [vp, sz, u32, u32, u32]
@@ -196,6 +198,21 @@ def fri_fold_eval(layer, log_n, log_b, rnd, beta_raw):
 
 
 # ---- sha / merkle ------------------------------------------------------------
+HASH_SHA256, HASH_FIELD = 0, 1
+
+
+def set_hash(kind):
+    """0 = SHA-256 (reference), 1 = field-native hash (configs[4]); affects merkle_*, prove, verify."""
+    lib().orc_set_hash(int(kind))
+
+
+def fieldhash_permute(state):
+    s = _u32(state).copy()
+    assert len(s) == 16
+    lib().orc_fieldhash_permute(_ptr(s))
+    return s
+
+
 def sha256(msg: bytes) -> bytes:
     out = C.create_string_buffer(32)
     lib().orc_sha256(msg, len(msg), out)

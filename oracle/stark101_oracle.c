@@ -569,16 +569,112 @@ void orc_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
 }
 
 /* ======================================================================== */
+/* Field-native Merkle hash (BASELINE.json configs[4])  */
+/* ======================================================================== */
+/* The reference has only SHA-256 (merkle.rs:1-2).  This Poseidon2-style permutation over GF(P)
+ * is the build's own definition ("parity: self-defined"); the spec is DESIGN.md section 8 and
+ * this code.  Width 16, S-box x^5 (gcd(5, P-1) = 1), 8 full + 22 partial rounds, external layer
+ * circ(2 M4, M4, M4, M4), internal layer J + diag(d).  A performance stand-in, not a vetted
+ * instance.  Digest = first 8 state words of perm(state) + state. */
+enum { ORC_HASH_SHA256 = 0, ORC_HASH_FIELD = 1 };
+static int g_hash_kind = ORC_HASH_SHA256;
+void orc_set_hash(int kind) { g_hash_kind = kind; }
+
+#define FH_T 16
+#define FH_RF 8
+#define FH_RP 22
+static uint32_t fh_rc_full[FH_RF][FH_T], fh_rc_part[FH_RP];
+static int fh_ready = 0;
+static const uint32_t fh_diag[FH_T] = {ORC_P - 2, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384};
+
+static void fh_init(void) {
+    if (fh_ready) return;
+    const char *tag = "zkstark_amd.fieldhash.v1";
+    size_t tl = strlen(tag);
+    for (uint32_t k = 0; k < FH_RF * FH_T + FH_RP; ++k) {
+        uint8_t msg[64], dig[32];
+        memcpy(msg, tag, tl);
+        msg[tl] = (uint8_t)k; msg[tl + 1] = (uint8_t)(k >> 8); msg[tl + 2] = (uint8_t)(k >> 16); msg[tl + 3] = (uint8_t)(k >> 24);
+        orc_sha256(msg, tl + 4, dig);
+        uint64_t v = 0;
+        for (int i = 0; i < 8; ++i) v = (v << 8) | dig[i];
+        uint32_t c = (uint32_t)(v % ORC_P);
+        if (k < FH_RF * FH_T) fh_rc_full[k / FH_T][k % FH_T] = c; else fh_rc_part[k - FH_RF * FH_T] = c;
+    }
+    fh_ready = 1;
+}
+static inline uint32_t fh_sbox(uint32_t x) { uint32_t x2 = fmul(x, x); return fmul(fmul(x2, x2), x); }
+/* 4x4 block: the linear map defined by this sequence of additions and doublings */
+static void fh_m4(uint32_t *x) {
+    uint32_t t0 = fadd(x[0], x[1]), t1 = fadd(x[2], x[3]);
+    uint32_t t2 = fadd(fadd(x[1], x[1]), t1), t3 = fadd(fadd(x[3], x[3]), t0);
+    uint32_t t1_4 = fadd(t1, t1); t1_4 = fadd(t1_4, t1_4);
+    uint32_t t0_4 = fadd(t0, t0); t0_4 = fadd(t0_4, t0_4);
+    uint32_t t4 = fadd(t1_4, t3), t5 = fadd(t0_4, t2);
+    uint32_t t6 = fadd(t3, t5), t7 = fadd(t2, t4);
+    x[0] = t6; x[1] = t5; x[2] = t7; x[3] = t4;
+}
+static void fh_external(uint32_t *s) {
+    for (int b = 0; b < 4; ++b) fh_m4(s + 4 * b);
+    uint32_t col[4];
+    for (int j = 0; j < 4; ++j) col[j] = fadd(fadd(s[j], s[4 + j]), fadd(s[8 + j], s[12 + j]));
+    for (int i = 0; i < FH_T; ++i) s[i] = fadd(s[i], col[i & 3]);
+}
+static void fh_internal(uint32_t *s) {
+    uint32_t sum = 0;
+    for (int i = 0; i < FH_T; ++i) sum = fadd(sum, s[i]);
+    for (int i = 0; i < FH_T; ++i) s[i] = fadd(fmul(s[i], fh_diag[i]), sum);
+}
+void orc_fieldhash_permute(uint32_t s[16]) {
+    fh_init();
+    fh_external(s);
+    for (int r = 0; r < FH_RF / 2; ++r) {
+        for (int i = 0; i < FH_T; ++i) s[i] = fh_sbox(fadd(s[i], fh_rc_full[r][i]));
+        fh_external(s);
+    }
+    for (int r = 0; r < FH_RP; ++r) {
+        s[0] = fh_sbox(fadd(s[0], fh_rc_part[r]));
+        fh_internal(s);
+    }
+    for (int r = FH_RF / 2; r < FH_RF; ++r) {
+        for (int i = 0; i < FH_T; ++i) s[i] = fh_sbox(fadd(s[i], fh_rc_full[r][i]));
+        fh_external(s);
+    }
+}
+static void fh_digest(const uint32_t in[16], uint8_t out[32]) {
+    uint32_t s[16];
+    memcpy(s, in, sizeof s);
+    orc_fieldhash_permute(s);
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = fadd(s[i], in[i]);
+        out[4 * i] = (uint8_t)(v >> 24); out[4 * i + 1] = (uint8_t)(v >> 16); out[4 * i + 2] = (uint8_t)(v >> 8); out[4 * i + 3] = (uint8_t)v;
+    }
+}
+static uint32_t fh_word(const uint8_t *p) { return (((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]) % ORC_P; }
+
+/* ======================================================================== */
 /* merkle.rs                                                                */
 /* ======================================================================== */
 
 /* merkle.rs:30-34: leaf = SHA256(v.to_be_bytes()) */
 static void leaf_hash(uint32_t v, uint8_t out[32]) {
+    if (g_hash_kind == ORC_HASH_FIELD) {     /* state = (v, 0, ..., 0, 1): the 1 separates leaves from inner nodes */
+        uint32_t in[16] = {0};
+        in[0] = v % ORC_P; in[15] = 1;
+        fh_digest(in, out);
+        return;
+    }
     uint8_t be[4] = {(uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v};
     orc_sha256(be, 4, out);
 }
 /* merkle.rs:42-45: parent = SHA256(left || right) */
 static void node_hash(const uint8_t *l, const uint8_t *r, uint8_t out[32]) {
+    if (g_hash_kind == ORC_HASH_FIELD) {     /* state = left digest || right digest (8 field elements each) */
+        uint32_t in[16];
+        for (int i = 0; i < 8; ++i) { in[i] = fh_word(l + 4 * i); in[8 + i] = fh_word(r + 4 * i); }
+        fh_digest(in, out);
+        return;
+    }
     uint8_t cat[64];
     memcpy(cat, l, 32); memcpy(cat + 32, r, 32);
     orc_sha256(cat, 64, out);

@@ -92,6 +92,12 @@ size_t orc_merkle_trace(const uint8_t *nodes, size_t m, size_t leaf, uint8_t *pa
 void orc_compute_root_from_path(uint32_t element, size_t index, const uint8_t *path,
                                 size_t path_len, uint8_t out[32]);
 
+/* Merkle hash selector for every function above and below: 0 = SHA-256 (the reference,
+ * merkle.rs:1-2), 1 = the build's field-native Poseidon2-style hash (BASELINE.json configs[4];
+ * self-defined, no reference counterpart).  The transcript always hashes with SHA-256. */
+void orc_set_hash(int kind);
+void orc_fieldhash_permute(uint32_t state[16]);
+
 /* ---- channel.rs -------------------------------------------------------- */
 typedef struct orc_channel {
     uint8_t state[32];

@@ -54,6 +54,7 @@ SYMBOLS = {
     "zk_ctx_setup_ms": (_dbl, [_vp]),
     "zk_ctx_device_bytes": (_sz, [_vp]),
     "zk_ctx_sync": (_int, [_vp]),
+    "zk_ctx_set_hash": (_int, [_vp, _int]),
     "zk_ctx_stream": (_vp, [_vp]),
     "zk_ctx_set_profiling": (_int, [_vp, _u32]),
     "zk_kernel_stats": (_int, [_vp, _vp, _sz, _int]),
@@ -71,6 +72,10 @@ SYMBOLS = {
     "zk_prove": (_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
     "zk_verify": (_int, [_vp, _sz, _u32, _u32, _u32]),
+    "zk_verify_ex": (_int, [_vp, _sz, _u32, _u32, _u32, _int]),
+    "zk_compute_root_from_path_ex": (_int, [_u32, _sz, _vp, _sz, _vp, _int]),
+    "zk_merkle_build_host_ex": (_int, [_int, _vp, _sz, _vp, _int]),
+    "zk_dev_merkle_build_ex": (_int, [_vp, _u32, _vp, _vp, _int]),
     "zk_verify_strict": (_int, [_vp, _sz, _vp, _u32, _u32, _u32]),
     "zk_proof_size": (_sz, [_sz]),
     "zk_proof_data_len": (_sz, [_u32, _u32]),

@@ -12,6 +12,7 @@
 #include "kernels.hpp"
 
 #include "field.hpp"
+#include "fieldhash.hpp"
 #include "sha256.hpp"
 
 namespace zk {
@@ -345,6 +346,19 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
 // digest is written once in a contiguous 2 KiB run.  All control flow is wave-uniform.  One launch lowers the tree by k levels; the last
 // <= 2^11 nodes are finished by a single workgroup that keeps the level in LDS.
 
+// Merkle hash selector: 0 = SHA-256 (merkle.rs:1-2), 1 = field-native hash (fieldhash.hpp).
+__constant__ FieldHashConsts g_fh_consts;
+
+template <int HASH> struct Hasher;
+template <> struct Hasher<0> {
+    static __device__ __forceinline__ Digest leaf(uint32_t v) { return sha256_leaf(v); }
+    static __device__ __forceinline__ Digest inner(const Digest& l, const Digest& r) { return sha256_inner(l, r); }
+};
+template <> struct Hasher<1> {
+    static __device__ __forceinline__ Digest leaf(uint32_t v) { return fieldhash_leaf(v, g_fh_consts); }
+    static __device__ __forceinline__ Digest inner(const Digest& l, const Digest& r) { return fieldhash_inner(l, r, g_fh_consts); }
+};
+
 constexpr int kMerkleThreads = 256;
 constexpr uint32_t kMerkleMaxK = 4;
 
@@ -370,7 +384,7 @@ __device__ __forceinline__ Digest lds_digest(const uint4* p) {
     return d;
 }
 
-template <bool LEAF>
+template <bool LEAF, int HASH>
 __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const uint32_t* vals, uint32_t* nodes,
                                                                         uint32_t depth_in, uint32_t k) {
     // per wave: k levels x 2 groups x 64 digests x 2 uint4
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const ui
         Digest d;
         const size_t pos = base + (size_t)i * 64 + lane;         // 64 consecutive inputs: coalesced
         if (LEAF) {
-            d = sha256_leaf(vals[pos]);
+            d = Hasher<HASH>::leaf(vals[pos]);
             store_digest(nodes, in_base + pos, d);
         } else {
             d = load_digest(nodes, in_base + pos);
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const ui
             const uint4* x = my + lvl * 256 + 4 * lane;          // children 2*lane, 2*lane+1 of the 128 buffered nodes
             Digest l = lds_digest(x), r = lds_digest(x + 2);
             __builtin_amdgcn_wave_barrier();
-            d = sha256_inner(l, r);
+            d = Hasher<HASH>::inner(l, r);
             idx >>= 1;
             ++lvl;
             store_digest(nodes, (((size_t)1 << (depth_in - lvl)) - 1) + (base >> lvl) + (size_t)idx * 64 + lane, d);
@@ -426,7 +440,7 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
 // When the launch produces the root (depth_in == j) and a mailbox is given, the root is also
 // written to host-mapped memory followed by a sequence number, so the host prover can poll for
 // it instead of paying a blit kernel + stream synchronisation per commitment.
-template <bool LEAF>
+template <bool LEAF, int HASH>
 __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in, uint32_t j,
                                                                uint32_t* mailbox, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2]
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* v
     for (uint32_t i = tid; i < cnt; i += kWgThreads) {
         Digest d;
         if (LEAF) {
-            d = sha256_leaf(vals[first + i]);
+            d = Hasher<HASH>::leaf(vals[first + i]);
             store_digest(nodes, in_base + first + i, d);
         } else {
             d = load_digest(nodes, in_base + first + i);
@@ -453,8 +467,8 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* v
         // in place: node u is written over child slot u after every thread of the level has read
         Digest d0, d1;
         const bool a0 = tid < w, a1 = tid + kWgThreads < w;       // w <= 512: at most two nodes per thread
-        if (a0) d0 = sha256_inner(lds_digest(&lvl[4 * tid]), lds_digest(&lvl[4 * tid + 2]));
-        if (a1) d1 = sha256_inner(lds_digest(&lvl[4 * (tid + kWgThreads)]), lds_digest(&lvl[4 * (tid + kWgThreads) + 2]));
+        if (a0) d0 = Hasher<HASH>::inner(lds_digest(&lvl[4 * tid]), lds_digest(&lvl[4 * tid + 2]));
+        if (a1) d1 = Hasher<HASH>::inner(lds_digest(&lvl[4 * (tid + kWgThreads)]), lds_digest(&lvl[4 * (tid + kWgThreads) + 2]));
         __syncthreads();
         if (a0) { lds_store(&lvl[2 * tid], d0); store_digest(nodes, out_base + tid, d0); }
         if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
@@ -474,9 +488,23 @@ static double merkle_bytes(bool leaf, uint32_t depth, uint32_t k) {
     double produced = (leaf ? in : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k));
     return (leaf ? 4.0 : 32.0) * in + 32.0 * produced;
 }
-static double merkle_ops(bool leaf, uint32_t depth, uint32_t k) {
+static double merkle_ops(bool leaf, uint32_t depth, uint32_t k, int hash) {
     double in = (double)((size_t)1 << depth);
-    return (leaf ? in * kShaLeafOps : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k)) * kShaInnerOps;
+    double lo = hash ? kFieldLeafOps : kShaLeafOps, io = hash ? kFieldInnerOps : kShaInnerOps;
+    return (leaf ? in * lo : 0.0) + in * (1.0 - 1.0 / (double)((size_t)1 << k)) * io;
+}
+
+static hipError_t ensure_fieldhash_consts() {
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
+    FieldHashConsts c;
+    fieldhash_make_consts(c);
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_fh_consts), &c, sizeof c);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
 }
 
 // Throughput phase: subtree launches (k <= 4 levels each) while the level has more than 2^18 nodes,
@@ -485,7 +513,11 @@ static double merkle_ops(bool leaf, uint32_t depth, uint32_t k) {
 constexpr uint32_t kMerkleLatencyLog = 18;
 
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
-                               uint32_t* mailbox, uint32_t seq) {
+                               uint32_t* mailbox, uint32_t seq, int hash) {
+    if (hash) {
+        hipError_t e = ensure_fieldhash_consts();
+        if (e != hipSuccess) return e;
+    }
     uint32_t depth = log_m;
     bool leaf = true;
     while (depth > kMerkleLatencyLog) {
@@ -494,9 +526,14 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         size_t lanes = (size_t)1 << (depth - k);                // >= 2^18: a multiple of the block size
         uint32_t blocks = (uint32_t)(lanes / kMerkleThreads);
         size_t sh = (size_t)(kMerkleThreads / 64) * k * 256 * sizeof(uint4);
-        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s, merkle_ops(leaf, depth, k));
-        if (leaf) hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
-        else hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s, merkle_ops(leaf, depth, k, hash));
+        if (hash) {
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+            else hipLaunchKernelGGL((merkle_subtree_kernel<false, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+        } else {
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<true, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+            else hipLaunchKernelGGL((merkle_subtree_kernel<false, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+        }
         leaf = false;
         depth -= k;
     }
@@ -507,9 +544,14 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         uint32_t j = (depth + launches - 1) / launches;
         uint32_t blocks = 1u << (depth - j);
         size_t sh = ((size_t)2 << j) * sizeof(uint4);
-        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(leaf, depth, j), s, merkle_ops(leaf, depth, j));
-        if (leaf) hipLaunchKernelGGL(merkle_wg_kernel<true>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
-        else hipLaunchKernelGGL(merkle_wg_kernel<false>, dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(leaf, depth, j), s, merkle_ops(leaf, depth, j, hash));
+        if (hash) {
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+            else hipLaunchKernelGGL((merkle_wg_kernel<false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+        } else {
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+            else hipLaunchKernelGGL((merkle_wg_kernel<false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+        }
         leaf = false;
         depth -= j;
     } while (depth > 0);

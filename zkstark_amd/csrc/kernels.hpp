@@ -24,7 +24,9 @@ enum KernelClass : int {
 };
 
 constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
-constexpr double kShaInnerOps = 2293.0;   // ... of one inner hash (two compressions, second with constant schedule)
+constexpr double kShaInnerOps = 2293.0;
+constexpr double kFieldLeafOps = 10200.0;   // field-native hash, one permutation (estimate from timing at equal VALU efficiency, +-5 %)
+constexpr double kFieldInnerOps = 10300.0;   // ... of one inner hash (two compressions, second with constant schedule)
 
 struct Profiler {
     uint32_t mask = 0;
@@ -132,8 +134,9 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof = nu
 // Merkle tree over m = 2^log_m u32 leaves.  nodes: (2m-1) * 8 words, heap order
 // (merkle.rs:14-51), each node the eight SHA-256 state words.
 // mailbox (optional): 10 words of host-mapped memory; word 0 <- seq after words 2..9 <- root state words.
+// hash: 0 = SHA-256 (the reference, merkle.rs:1-2), 1 = field-native hash (fieldhash.hpp, configs[4]).
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
-                               uint32_t* mailbox = nullptr, uint32_t seq = 0);
+                               uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
 
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,

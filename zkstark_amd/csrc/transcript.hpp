@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "field.hpp"
+#include "fieldhash.hpp"
 #include "sha256.hpp"
 
 namespace zk {
@@ -64,26 +65,45 @@ inline size_t proof_data_len(uint32_t log_n, uint32_t log_b) {
     return len;
 }
 
-// merkle.rs:82-110
-inline void compute_root_from_path(uint32_t element, size_t index, const uint8_t* path, size_t plen, uint8_t out[32]) {
-    index += ((size_t)1 << plen) - 1;
-    uint8_t cur[32];
-    {
-        uint8_t be[4] = {(uint8_t)(element >> 24), (uint8_t)(element >> 16), (uint8_t)(element >> 8), (uint8_t)element};
-        Sha256 h; h.update(be, 4); h.finalize(cur);
+// Merkle hash on the host (verifier): hash 0 = SHA-256 (merkle.rs:30-34, :42-45), 1 = field-native (fieldhash.hpp)
+inline const FieldHashConsts& host_fieldhash_consts() {
+    static const FieldHashConsts c = [] { FieldHashConsts t; fieldhash_make_consts(t); return t; }();
+    return c;
+}
+inline void bytes_to_digest(const uint8_t* b, Digest& d) {
+    for (int i = 0; i < 8; ++i) d.w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+}
+inline void host_leaf_hash(uint32_t element, uint8_t out[32], int hash) {
+    if (hash) { digest_words_to_bytes(fieldhash_leaf(element, host_fieldhash_consts()).w, out); return; }
+    uint8_t be[4] = {(uint8_t)(element >> 24), (uint8_t)(element >> 16), (uint8_t)(element >> 8), (uint8_t)element};
+    Sha256 h; h.update(be, 4); h.finalize(out);
+}
+inline void host_node_hash(const uint8_t* l, const uint8_t* r, uint8_t out[32], int hash) {
+    if (hash) {
+        Digest dl, dr;
+        bytes_to_digest(l, dl); bytes_to_digest(r, dr);
+        digest_words_to_bytes(fieldhash_inner(dl, dr, host_fieldhash_consts()).w, out);
+        return;
     }
+    Sha256 h; h.update(l, 32); h.update(r, 32); h.finalize(out);
+}
+
+// merkle.rs:82-110
+inline void compute_root_from_path(uint32_t element, size_t index, const uint8_t* path, size_t plen, uint8_t out[32], int hash = 0) {
+    index += ((size_t)1 << plen) - 1;
+    uint8_t cur[32], nxt[32];
+    host_leaf_hash(element, cur, hash);
     for (size_t k = 0; k < plen; ++k) {
-        Sha256 h;
-        if (index % 2 == 0) { h.update(path + 32 * k, 32); h.update(cur, 32); index -= 2; }
-        else { h.update(cur, 32); h.update(path + 32 * k, 32); index -= 1; }
-        h.finalize(cur);
+        if (index % 2 == 0) { host_node_hash(path + 32 * k, cur, nxt, hash); index -= 2; }
+        else { host_node_hash(cur, path + 32 * k, nxt, hash); index -= 1; }
+        memcpy(cur, nxt, 32);
         index >>= 1;
     }
     memcpy(out, cur, 32);
 }
 
 // proof.rs:15-149 with the literals generalised.  Returns 0 or the negative index of the failed check.
-inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last) {
+inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last, int hash = 0) {
     if (log_n < 2 || log_b < 1 || log_n + log_b > 30) return -1;
     const size_t n = (size_t)1 << log_n, B = (size_t)1 << log_b, N = n << log_b, R = log_n, L = log_n + log_b;
     const uint8_t* p = data;
@@ -140,10 +160,10 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
     uint8_t root[32];
     if (fpl[0] != L || fpl[1] != L || fpl[2] != L || fpl[3] != L) return -3;
     // proof.rs:80-95
-    compute_root_from_path(fv[0], tp, fp[0], fpl[0], root);         if (memcmp(root, f_root, 32)) return -4;
-    compute_root_from_path(fv[1], tp + B, fp[1], fpl[1], root);     if (memcmp(root, f_root, 32)) return -5;
-    compute_root_from_path(fv[2], tp + 2 * B, fp[2], fpl[2], root); if (memcmp(root, f_root, 32)) return -6;
-    compute_root_from_path(fv[3], tp, fp[3], fpl[3], root);         if (memcmp(root, roots[0], 32)) return -7;
+    compute_root_from_path(fv[0], tp, fp[0], fpl[0], root, hash);         if (memcmp(root, f_root, 32)) return -4;
+    compute_root_from_path(fv[1], tp + B, fp[1], fpl[1], root, hash);     if (memcmp(root, f_root, 32)) return -5;
+    compute_root_from_path(fv[2], tp + 2 * B, fp[2], fpl[2], root, hash); if (memcmp(root, f_root, 32)) return -6;
+    compute_root_from_path(fv[3], tp, fp[3], fpl[3], root, hash);         if (memcmp(root, roots[0], 32)) return -7;
     // proof.rs:101-126
     const uint32_t inv2 = invmod(2);
     for (size_t k = 0; k < R; ++k) {
@@ -158,9 +178,9 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
     for (size_t k = 0; k < R; ++k) {
         size_t size = N >> k;
         if (plx[k] != L - k || plnx[k] != L - k) return -(int)(200 + k);
-        compute_root_from_path(lx[k], tp % size, lpx[k], plx[k], root);
+        compute_root_from_path(lx[k], tp % size, lpx[k], plx[k], root, hash);
         if (memcmp(root, roots[k], 32)) return -(int)(300 + k);
-        compute_root_from_path(lnx[k], (tp + size / 2) % size, lpnx[k], plnx[k], root);
+        compute_root_from_path(lnx[k], (tp + size / 2) % size, lpnx[k], plnx[k], root, hash);
         if (memcmp(root, roots[k], 32)) return -(int)(400 + k);
     }
     return 0;

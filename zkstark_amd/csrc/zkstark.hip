@@ -296,6 +296,7 @@ struct zk_ctx {
     uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: [seq, -, root words 0..7]
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
     uint32_t mail_seq = 0;
+    int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
     size_t gather_cap = 0;
     size_t device_bytes = 0;
     double setup_ms = 0;
@@ -348,7 +349,7 @@ int do_lde(zk_ctx* c) {
 int do_merkle(zk_ctx* c, uint32_t layer) {
     c->mail_seq += 1;
     HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer),
-                               c->d_trees + c->tree_off[layer], c->stream, prof_of(c), c->d_mailbox, c->mail_seq));
+                               c->d_trees + c->tree_off[layer], c->stream, prof_of(c), c->d_mailbox, c->mail_seq, c->hash));
     return ZK_OK;
 }
 
@@ -591,6 +592,13 @@ int zk_ctx_sync(zk_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
+int zk_ctx_set_hash(zk_ctx* c, int hash_kind) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_ctx_set_hash: unknown hash %d", hash_kind);
+    c->hash = hash_kind;
+    return ZK_OK;
+}
+
 int zk_ctx_set_profiling(zk_ctx* c, uint32_t class_mask) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
     c->prof.mask = class_mask & ((1u << K_COUNT) - 1u);
@@ -734,11 +742,15 @@ int zk_last_transcript(const zk_ctx* c, zk_transcript_info* out) {
     return ZK_OK;
 }
 
-int zk_verify(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last) {
+int zk_verify_ex(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last, int hash_kind) {
     if (!proof) return fail(ZK_ERR_INVALID, "zk_verify: null proof");
-    int rc = verify_proof(proof, len, log_n, log_b, public_last);
+    if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_verify: unknown hash %d", hash_kind);
+    int rc = verify_proof(proof, len, log_n, log_b, public_last, hash_kind);
     if (rc) return fail(ZK_ERR_VERIFY, "proof rejected at check %d (proof.rs:15-149)", rc);
     return ZK_OK;
+}
+int zk_verify(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last) {
+    return zk_verify_ex(proof, len, log_n, log_b, public_last, ZK_HASH_SHA256);
 }
 
 int zk_verify_strict(const uint8_t* proof, size_t len, const uint8_t state[32], uint32_t log_n, uint32_t log_b, uint32_t public_last) {
@@ -751,10 +763,14 @@ int zk_verify_strict(const uint8_t* proof, size_t len, const uint8_t state[32], 
 size_t zk_proof_size(size_t data_len) { return 48 + data_len; }   // proof.rs:151-154: size_of::<Proof>() = 32 + 16
 size_t zk_proof_data_len(uint32_t log_n, uint32_t log_b) { return proof_data_len(log_n, log_b); }
 
-int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t* path, size_t path_len, uint8_t out[32]) {
-    if ((!path && path_len) || !out || path_len > 62) return fail(ZK_ERR_INVALID, "zk_compute_root_from_path: bad argument");
-    compute_root_from_path(element, index, path, path_len, out);
+int zk_compute_root_from_path_ex(uint32_t element, size_t index, const uint8_t* path, size_t path_len, uint8_t out[32], int hash_kind) {
+    if ((!path && path_len) || !out || path_len > 62 || (hash_kind != 0 && hash_kind != 1))
+        return fail(ZK_ERR_INVALID, "zk_compute_root_from_path: bad argument");
+    compute_root_from_path(element, index, path, path_len, out, hash_kind);
     return ZK_OK;
+}
+int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t* path, size_t path_len, uint8_t out[32]) {
+    return zk_compute_root_from_path_ex(element, index, path, path_len, out, ZK_HASH_SHA256);
 }
 
 // ---- Channel -------------------------------------------------------------------
@@ -850,10 +866,13 @@ int zk_dev_gather(const uint32_t* d_src, const uint64_t* d_offsets, uint32_t cou
 }
 
 // ---- stand-alone primitives --------------------------------------------------------
-int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
-    if (!d_vals || !d_nodes || log_m > 30) return fail(ZK_ERR_INVALID, "zk_dev_merkle_build: bad argument");
-    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream, dev_prof()));
+int zk_dev_merkle_build_ex(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream, int hash_kind) {
+    if (!d_vals || !d_nodes || log_m > 30 || (hash_kind != 0 && hash_kind != 1)) return fail(ZK_ERR_INVALID, "zk_dev_merkle_build: bad argument");
+    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream, dev_prof(), nullptr, 0, hash_kind));
     return ZK_OK;
+}
+int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
+    return zk_dev_merkle_build_ex(d_vals, log_m, d_nodes, stream, ZK_HASH_SHA256);
 }
 
 int zk_dev_merkle_node(const uint32_t* d_nodes, size_t index, uint8_t out[32], void* stream) {
@@ -866,7 +885,12 @@ int zk_dev_merkle_node(const uint32_t* d_nodes, size_t index, uint8_t out[32], v
 }
 
 int zk_merkle_build_host(int device, const uint32_t* vals, size_t m, uint8_t* nodes_out) {
+    return zk_merkle_build_host_ex(device, vals, m, nodes_out, ZK_HASH_SHA256);
+}
+
+int zk_merkle_build_host_ex(int device, const uint32_t* vals, size_t m, uint8_t* nodes_out, int hash_kind) {
     if (!vals || !nodes_out) return fail(ZK_ERR_INVALID, "zk_merkle_build_host: null argument");
+    if (hash_kind != 0 && hash_kind != 1) return fail(ZK_ERR_INVALID, "zk_merkle_build_host: unknown hash %d", hash_kind);
     if (m == 0 || (m & (m - 1)) || m > ((size_t)1 << 30))      // merkle.rs:16-21 asserts a power of two
         return fail(ZK_ERR_INVALID, "zk_merkle_build_host: size %zu is not a power of two (merkle.rs:18)", m);
     uint32_t log_m = 0;
@@ -881,7 +905,7 @@ int zk_merkle_build_host(int device, const uint32_t* vals, size_t m, uint8_t* no
     std::vector<uint32_t> host(words);
     do {
         if (hipMemcpy(d_vals, vals, m * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "H2D failed"); break; }
-        if (launch_merkle_build(d_vals, log_m, d_nodes, nullptr) != hipSuccess) { rc = fail(ZK_ERR_HIP, "merkle launch failed"); break; }
+        if (launch_merkle_build(d_vals, log_m, d_nodes, nullptr, nullptr, nullptr, 0, hash_kind) != hipSuccess) { rc = fail(ZK_ERR_HIP, "merkle launch failed"); break; }
         if (hipMemcpy(host.data(), d_nodes, words * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "D2H failed: %s", hipGetErrorString(hipGetLastError())); break; }
     } while (0);
     (void)hipFree(d_vals); (void)hipFree(d_nodes);

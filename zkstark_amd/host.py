@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import ZkError, check
 
 P = 3221225473  # main.rs:13
+HASHES = {"sha256": 0, "field": 1}   # Merkle hash: the reference's SHA-256, or the field-native one (configs[4])
 
 
 def _u32arr(a):
@@ -107,43 +108,45 @@ class Channel:
 class Proof:
     """proof.rs:5-154.  verify() raises ZkError where the reference panics."""
 
-    def __init__(self, state, data, log_n=10, log_blowup=3, public_last=2338775057):   # proof.rs:11
+    def __init__(self, state, data, log_n=10, log_blowup=3, public_last=2338775057, hash="sha256"):   # proof.rs:11
         self.state, self.data = bytes(state), bytes(data)
         self.log_n, self.log_blowup, self.public_last = log_n, log_blowup, public_last
+        self.hash = hash
 
     def verify(self, strict=False):                  # proof.rs:15
         """strict=True also replays the channel: challenges must come from the transcript and `state`
         must be its final state (the reference trusts the proof for both, proof.rs:22-37)."""
-        if strict:
+        if strict and self.hash == "sha256":
             check(_lib.load().zk_verify_strict(self.data, len(self.data), self.state, self.log_n, self.log_blowup,
                                                self.public_last))
         else:
-            check(_lib.load().zk_verify(self.data, len(self.data), self.log_n, self.log_blowup, self.public_last))
+            check(_lib.load().zk_verify_ex(self.data, len(self.data), self.log_n, self.log_blowup, self.public_last,
+                                           HASHES[self.hash]))
 
     def size(self):                                  # proof.rs:151
         return _lib.load().zk_proof_size(len(self.data))
 
 
-def compute_root_from_path(element, index, path):
+def compute_root_from_path(element, index, path, hash="sha256"):
     """merkle.rs:82-110."""
     flat = b"".join(bytes(h) for h in path)
     out = C.create_string_buffer(32)
-    check(_lib.load().zk_compute_root_from_path(element, index, flat, len(path), out))
+    check(_lib.load().zk_compute_root_from_path_ex(element, index, flat, len(path), out, HASHES[hash]))
     return out.raw
 
 
 class Merkle:
     """merkle.rs:6-79: SHA-256 heap built on the GPU; merkle[i], merkle.trace(i)."""
 
-    def __init__(self, size, data, device=0):        # Merkle::new, merkle.rs:14
+    def __init__(self, size, data, device=0, hash="sha256"):        # Merkle::new, merkle.rs:14
         vals = _u32arr(list(data) if not isinstance(data, np.ndarray) else data)
         if len(vals) != size:
             raise ZkError(-1, f"Merkle.new: size {size} != len(data) {len(vals)}")
         self.size = size
         self.nodes = np.zeros((max(2 * size - 1, 1), 32), dtype=np.uint8)
-        check(_lib.load().zk_merkle_build_host(device, _ptr(vals), size, _ptr(self.nodes)))
+        check(_lib.load().zk_merkle_build_host_ex(device, _ptr(vals), size, _ptr(self.nodes), HASHES[hash]))
 
-    new = classmethod(lambda cls, size, data, device=0: cls(size, data, device))
+    new = classmethod(lambda cls, size, data, device=0, hash="sha256": cls(size, data, device, hash))
 
     def __getitem__(self, i):                        # merkle.rs:74-79
         return bytes(self.nodes[i])
@@ -184,12 +187,14 @@ def lde(trace, log_n, log_blowup, device=0):
 class Context:
     """Device-resident prover state for one (log_n, log_blowup): zk_ctx."""
 
-    def __init__(self, log_n=10, log_blowup=3, device=0):
-        self.log_n, self.log_blowup, self.device = log_n, log_blowup, device
+    def __init__(self, log_n=10, log_blowup=3, device=0, hash="sha256"):
+        self.log_n, self.log_blowup, self.device, self.hash = log_n, log_blowup, device, hash
         self.n, self.B = 1 << log_n, 1 << log_blowup
         self.N, self.rounds = self.n * self.B, log_n
         self._h = C.c_void_p()
         check(_lib.load().zk_ctx_create(device, log_n, log_blowup, C.byref(self._h)))
+        if hash != "sha256":
+            check(_lib.load().zk_ctx_set_hash(self._h, HASHES[hash]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -277,7 +282,7 @@ class Context:
             t = _u32arr(trace)
             check(_lib.load().zk_prove(self._h, _ptr(t), len(t), buf, cap, C.byref(n), st))
         info = self.last_transcript()
-        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, info.public_last)
+        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, info.public_last, self.hash)
 
     def last_transcript(self):
         info = _lib.TranscriptInfo()
