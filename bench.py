@@ -42,7 +42,7 @@ def parse():
                     help="Merkle hash: the reference's SHA-256 (the benchmark), or the field-native hash of configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="also report throughput with this many proofs in flight (1 = skip)")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=20, help="oracle sample: domain 2^(this+blowup)")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=21, help="oracle sample: domain 2^(this+blowup)")
     return ap.parse_args()
 
 
