@@ -280,11 +280,9 @@ hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uin
 //   p2 = (f(g^2 x) - f(g x)^2 - f(x)^2) (x - g^(n-3))(x - g^(n-2))(x - g^(n-1)) / (x^n - 1)
 //   cp = alpha0 p0 + alpha1 p1 + alpha2 p2
 // with f(g x_i) = f[i+B], f(g^2 x_i) = f[i+2B] (indices mod N); x^n - 1 depends on i mod B only.
-__global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
+__device__ __forceinline__ uint32_t compose_at(const ComposeArgs& a, size_t i) {
     const size_t N = (size_t)1 << a.logN;
     const uint32_t B = 1u << a.log_b;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
     const size_t i1 = (i + B) & (N - 1), i2 = (i + 2 * (size_t)B) & (N - 1);
     uint32_t f0 = a.f[i], f1 = a.f[i1], f2 = a.f[i2];
     uint32_t inv0 = a.inv_xm1[i], inv2 = a.inv_xm1[i2];
@@ -296,7 +294,13 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
     // data*data products carry R^-1; bring f2 to the same scale, fix with the R^2 in y
     uint32_t num = sub(sub(mont_mul(f2, 1u), mont_mul(f1, f1)), mont_mul(f0, f0));
     uint32_t t2 = mont_mul(num, y);
-    a.cp[i] = add(add(t0, t1), t2);
+    return add(add(t0, t1), t2);
+}
+
+__global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << a.logN)) return;
+    a.cp[i] = compose_at(a, i);
 }
 
 hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof) {
@@ -312,15 +316,19 @@ hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof) {
 // ===========================================================================
 // next[i] = (e[i] + e[i+m/2])/2 + beta (e[i] - e[i+m/2]) / (2 x_i),  x_i = (w h^i)^(2^r)
 // (identity pinned by fri_test, polynomial.rs:418-425, and used at proof.rs:110-113).
-__global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a) {
+__device__ __forceinline__ uint32_t fold_at(const FoldArgs& a, size_t i) {
     const size_t half = (size_t)1 << (a.log_m - 1);
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= half) return;
     uint32_t u = a.in[i], v = a.in[i + half];
     uint32_t xinv = pow_lookup(a.hinv, (uint32_t)(i << a.round));   // h^(-2^r i), i 2^r < N/2
     uint32_t s = mont_mul(add(u, v), a.inv2_mont);
     uint32_t d = mont_mul(mont_mul(sub(u, v), xinv), a.c_mont);
-    a.out[i] = add(s, d);
+    return add(s, d);
+}
+
+__global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << (a.log_m - 1))) return;
+    a.out[i] = fold_at(a, i);
 }
 
 hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
@@ -359,6 +367,22 @@ template <> struct Hasher<1> {
     static __device__ __forceinline__ Digest inner(const Digest& l, const Digest& r) { return fieldhash_inner(l, r, g_fh_consts); }
 };
 
+// Where the leaf values of a tree come from.  The prover fuses the elementwise producer of a layer
+// into the leaf hashing of its commitment: the value is computed, written to the layer and hashed
+// in one pass (no separate fold / compose launch, the layer is never re-read for hashing).
+struct PlainSrc {
+    const uint32_t* vals;
+    __device__ __forceinline__ uint32_t load(size_t pos) const { return vals[pos]; }
+};
+struct FoldSrc {       // FRI layer r+1 = fold(layer r, beta): prover.rs:198-211 + :214
+    FoldArgs a;
+    __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = fold_at(a, pos); a.out[pos] = v; return v; }
+};
+struct ComposeSrc {    // cp layer 0 from f_eval: prover.rs:101-173 + :176
+    ComposeArgs a;
+    __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = compose_at(a, pos); a.cp[pos] = v; return v; }
+};
+
 constexpr int kMerkleThreads = 256;
 constexpr uint32_t kMerkleMaxK = 4;
 
@@ -384,8 +408,8 @@ __device__ __forceinline__ Digest lds_digest(const uint4* p) {
     return d;
 }
 
-template <bool LEAF, int HASH>
-__global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const uint32_t* vals, uint32_t* nodes,
+template <class SRC, bool LEAF, int HASH>
+__global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src, uint32_t* nodes,
                                                                         uint32_t depth_in, uint32_t k) {
     // per wave: k levels x 2 groups x 64 digests x 2 uint4
     extern __shared__ __attribute__((aligned(16))) uint4 stage[];
@@ -399,7 +423,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(const ui
         Digest d;
         const size_t pos = base + (size_t)i * 64 + lane;         // 64 consecutive inputs: coalesced
         if (LEAF) {
-            d = Hasher<HASH>::leaf(vals[pos]);
+            d = Hasher<HASH>::leaf(src.load(pos));
             store_digest(nodes, in_base + pos, d);
         } else {
             d = load_digest(nodes, in_base + pos);
@@ -440,10 +464,11 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
 // When the launch produces the root (depth_in == j) and a mailbox is given, the root is also
 // written to host-mapped memory followed by a sequence number, so the host prover can poll for
 // it instead of paying a blit kernel + stream synchronisation per commitment.
-template <bool LEAF, int HASH>
-__global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* vals, uint32_t* nodes, uint32_t depth_in, uint32_t j,
+template <class SRC, bool LEAF, int HASH>
+__global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t j,
                                                                uint32_t* mailbox, uint32_t seq) {
-    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2]
+    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2], then the 16 KiB schedule exchange
+    uint32_t* xch = reinterpret_cast<uint32_t*>(lvl + ((size_t)2 << j));
     const uint32_t tid = threadIdx.x;
     const uint32_t cnt = 1u << j;
     const size_t first = (size_t)blockIdx.x << j;                 // first input of this workgroup
@@ -452,7 +477,7 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* v
     for (uint32_t i = tid; i < cnt; i += kWgThreads) {
         Digest d;
         if (LEAF) {
-            d = Hasher<HASH>::leaf(vals[first + i]);
+            d = Hasher<HASH>::leaf(src.load(first + i));
             store_digest(nodes, in_base + first + i, d);
         } else {
             d = load_digest(nodes, in_base + first + i);
@@ -464,6 +489,69 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(const uint32_t* v
     for (uint32_t t = 1; t <= j; ++t) {
         const uint32_t w = cnt >> t;                              // nodes of this level in the workgroup
         const size_t out_base = (((size_t)1 << (depth_in - t)) - 1) + (first >> t);
+        if (HASH == 0 && w <= 128) {
+            // Latency-bound level with idle waves: split each SHA-256 between a main lane (waves 0-1:
+            // the 2 x 64 rounds) and a helper lane (waves 2-3: the 48 message-schedule steps of block 1),
+            // 16 rounds at a time through a double-buffered LDS exchange.  The main lane's critical
+            // path drops from 2293 to ~1850 instructions.
+            const bool is_main = tid < 128;
+            const uint32_t node = tid & 127u;
+            const bool active = node < w;
+            uint32_t wv[16];
+            uint32_t st[8];
+            if (active) {
+                Digest l = lds_digest(&lvl[4 * node]), r = lds_digest(&lvl[4 * node + 2]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { wv[i] = l.w[i]; wv[8 + i] = r.w[i]; st[i] = SHA_IV[i]; }
+            }
+            uint32_t* xb0 = xch;                                   // [16][128]
+            uint32_t* xb1 = xch + 16 * 128;
+            // phase A: rounds 0-15 | W16-31 -> xb0
+            if (active) {
+                if (is_main) sha256_rounds16<0>(st, wv);
+                else { sha256_schedule16(wv);
+#pragma unroll
+                       for (int i = 0; i < 16; ++i) xb0[i * 128 + node] = wv[i]; }
+            }
+            __syncthreads();
+            // phase B: rounds 16-31 | W32-47 -> xb1
+            if (active) {
+                if (is_main) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) wv[i] = xb0[i * 128 + node];
+                    sha256_rounds16<16>(st, wv);
+                } else { sha256_schedule16(wv);
+#pragma unroll
+                         for (int i = 0; i < 16; ++i) xb1[i * 128 + node] = wv[i]; }
+            }
+            __syncthreads();
+            // phase C: rounds 32-47 | W48-63 -> xb0
+            if (active) {
+                if (is_main) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) wv[i] = xb1[i * 128 + node];
+                    sha256_rounds16<32>(st, wv);
+                } else { sha256_schedule16(wv);
+#pragma unroll
+                         for (int i = 0; i < 16; ++i) xb0[i * 128 + node] = wv[i]; }
+            }
+            __syncthreads();
+            // phase D: rounds 48-63, feed-forward, padding block
+            Digest d0;
+            if (active && is_main) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wv[i] = xb0[i * 128 + node];
+                sha256_rounds16<48>(st, wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d0.w[i] = st[i] + SHA_IV[i];
+                uint32_t pad[16] = {0x80000000u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 512u};
+                sha256_compress(d0.w, pad);
+            }
+            __syncthreads();                                       // every read of lvl and xch done
+            if (active && is_main) { lds_store(&lvl[2 * node], d0); store_digest(nodes, out_base + node, d0); }
+            __syncthreads();
+            continue;
+        }
         // in place: node u is written over child slot u after every thread of the level has read
         Digest d0, d1;
         const bool a0 = tid < w, a1 = tid + kWgThreads < w;       // w <= 512: at most two nodes per thread
@@ -512,27 +600,31 @@ static hipError_t ensure_fieldhash_consts() {
 // of up to 10 levels each.
 constexpr uint32_t kMerkleLatencyLog = 18;
 
-hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
-                               uint32_t* mailbox, uint32_t seq, int hash) {
+template <class SRC>
+static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                                 uint32_t* mailbox, uint32_t seq, int hash) {
     if (hash) {
         hipError_t e = ensure_fieldhash_consts();
         if (e != hipSuccess) return e;
     }
     uint32_t depth = log_m;
     bool leaf = true;
+    const PlainSrc none{nullptr};
+    // the first launch reads its leaves through SRC: replace the plain 4 B/leaf read by the source's bytes
+    auto first_bytes = [&](double b) { return leaf ? b - 4.0 * (double)((size_t)1 << log_m) + src_bytes : b; };
     while (depth > kMerkleLatencyLog) {
         uint32_t k = depth - kMerkleLatencyLog;
         if (k > kMerkleMaxK) k = kMerkleMaxK;
         size_t lanes = (size_t)1 << (depth - k);                // >= 2^18: a multiple of the block size
         uint32_t blocks = (uint32_t)(lanes / kMerkleThreads);
         size_t sh = (size_t)(kMerkleThreads / 64) * k * 256 * sizeof(uint4);
-        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, merkle_bytes(leaf, depth, k), s, merkle_ops(leaf, depth, k, hash));
+        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, first_bytes(merkle_bytes(leaf, depth, k)), s, merkle_ops(leaf, depth, k, hash));
         if (hash) {
-            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
-            else hipLaunchKernelGGL((merkle_subtree_kernel<false, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k);
+            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k);
         } else {
-            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<true, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
-            else hipLaunchKernelGGL((merkle_subtree_kernel<false, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, vals, nodes, depth, k);
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k);
+            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k);
         }
         leaf = false;
         depth -= k;
@@ -543,19 +635,33 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
         if (launches == 0) launches = 1;
         uint32_t j = (depth + launches - 1) / launches;
         uint32_t blocks = 1u << (depth - j);
-        size_t sh = ((size_t)2 << j) * sizeof(uint4);
-        ScopedKernelTimer tm(prof, K_MERKLE_TOP, merkle_bytes(leaf, depth, j), s, merkle_ops(leaf, depth, j, hash));
+        size_t sh = ((size_t)2 << j) * sizeof(uint4) + 2 * 16 * 128 * sizeof(uint32_t);
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, first_bytes(merkle_bytes(leaf, depth, j)), s, merkle_ops(leaf, depth, j, hash));
         if (hash) {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
-            else hipLaunchKernelGGL((merkle_wg_kernel<false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq);
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq);
         } else {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
-            else hipLaunchKernelGGL((merkle_wg_kernel<false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, vals, nodes, depth, j, mailbox, seq);
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq);
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq);
         }
         leaf = false;
         depth -= j;
     } while (depth > 0);
     return hipGetLastError();
+}
+
+hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                               uint32_t* mailbox, uint32_t seq, int hash) {
+    return merkle_build_t(PlainSrc{vals}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, mailbox, seq, hash);
+}
+// fold + commit of the folded layer (a.out receives it): one pass
+hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {
+    uint32_t log_out = a.log_m - 1;
+    return merkle_build_t(FoldSrc{a}, 12.0 * (double)((size_t)1 << log_out), log_out, nodes, s, prof, mailbox, seq, hash);
+}
+// composition + commit of cp layer 0 (a.cp receives it): one pass
+hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {
+    return merkle_build_t(ComposeSrc{a}, 8.0 * (double)((size_t)1 << a.logN), a.logN, nodes, s, prof, mailbox, seq, hash);
 }
 
 // ===========================================================================

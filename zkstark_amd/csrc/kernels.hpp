@@ -138,6 +138,12 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof = nu
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                                uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
 
+// Fused producer + commitment: the layer is computed, stored and leaf-hashed in one pass.
+hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
+                              uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
+hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
+                                 uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
+
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
                          uint32_t* out, hipStream_t s, Profiler* prof = nullptr);

@@ -88,6 +88,32 @@ ZK_SHA_HD void sha256_compress(uint32_t st[8], uint32_t w[16]) {
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
 
+// The same compression in 16-round slices, for the split main/helper schedule of the latency-bound
+// tree levels (kernels.hip, merkle_wg_kernel): rounds I0 .. I0+15 on already-scheduled words, and
+// the in-place step W[t+16] = s1(W[t+14]) + W[t+9] + s0(W[t+1]) + W[t] for 16 consecutive t.
+template <int I0>
+ZK_SHA_HD void sha256_rounds16(uint32_t (&st)[8], const uint32_t (&w)[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t S1 = sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25));
+        uint32_t t1 = (h + S1 + sha_ch(e, f, g)) + (SHA_K[I0 + i] + w[i]);
+        uint32_t S0 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22));
+        uint32_t mj = sha_maj(a, b, c);
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+    }
+    st[0] = a; st[1] = b; st[2] = c; st[3] = d; st[4] = e; st[5] = f; st[6] = g; st[7] = h;
+}
+ZK_SHA_HD void sha256_schedule16(uint32_t (&w)[16]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        uint32_t w1 = w[(t + 1) & 15], w14 = w[(t + 14) & 15];
+        uint32_t s0 = sha_xor3(sha_rotr(w1, 7), sha_rotr(w1, 18), w1 >> 3);
+        uint32_t s1 = sha_xor3(sha_rotr(w14, 17), sha_rotr(w14, 19), w14 >> 10);
+        w[t] = (w[t] + s0 + w[(t + 9) & 15]) + s1;
+    }
+}
+
 // merkle.rs:30-34: SHA256(v.to_be_bytes())
 ZK_SHA_HD Digest sha256_leaf(uint32_t v) {
     uint32_t w[16] = {v, 0x80000000u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32u};

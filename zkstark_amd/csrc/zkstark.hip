@@ -232,9 +232,9 @@ int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t
 }
 
 // prover.rs:101-173 pointwise on the domain.
-int dom_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last,
-                const uint32_t alpha_raw[3], hipStream_t s, Profiler* prof) {
-    ComposeArgs a{};
+int compose_args(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last,
+                 const uint32_t alpha_raw[3], ComposeArgs& a) {
+    a = ComposeArgs{};
     a.f = d_f; a.inv_xm1 = d->d_inv_xm1; a.cp = d_cp;
     a.logN = d->L; a.log_b = d->log_b;
     a.htab = d->H.view();
@@ -251,21 +251,34 @@ int dom_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t f
         a.zz[r] = to_mont(to_mont(mulmod(a2, invmod(den))));
         xn = mulmod(xn, hn);
     }
+    return ZK_OK;
+}
+int dom_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last,
+                const uint32_t alpha_raw[3], hipStream_t s, Profiler* prof) {
+    ComposeArgs a;
+    int rc = compose_args(d, d_f, d_cp, first, last, alpha_raw, a);
+    if (rc) return rc;
     HIPCHK(launch_compose(a, s, prof));
     return ZK_OK;
 }
 
 // polynomial.rs:385-400 + prover.rs:204-211 in evaluation form: layer of 2^log_m values at
 // x_i = (shift h^i)^(2^round) -> 2^(log_m-1) values.
-int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw,
-             hipStream_t s, Profiler* prof) {
+int fold_args(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw, FoldArgs& a) {
     if (log_m < 1 || log_m + round != d->L) return fail(ZK_ERR_INVALID, "fold: layer size 2^%u does not match round %u of a 2^%u domain", log_m, round, d->L);
-    FoldArgs a{};
+    a = FoldArgs{};
     a.in = d_in; a.out = d_out; a.log_m = log_m; a.round = round;
     a.hinv = d->Hinv.view(); a.L = d->L;
     a.inv2_mont = d->inv2_mont;
     uint32_t winv = invmod(powmod(d->shift, (uint64_t)1 << round));
     a.c_mont = to_mont(mulmod(mulmod(beta_raw % P, winv), invmod(2)));
+    return ZK_OK;
+}
+int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw,
+             hipStream_t s, Profiler* prof) {
+    FoldArgs a;
+    int rc = fold_args(d, d_in, d_out, log_m, round, beta_raw, a);
+    if (rc) return rc;
     HIPCHK(launch_fri_fold(a, s, prof));
     return ZK_OK;
 }
@@ -353,6 +366,24 @@ int do_merkle(zk_ctx* c, uint32_t layer) {
     return ZK_OK;
 }
 
+// Fused stages of the one-call prover: the producer of a layer runs inside the leaf hashing of its tree.
+int do_compose_commit(zk_ctx* c, const uint32_t alpha_raw[3]) {
+    ComposeArgs a;
+    int rc = compose_args(c->dom, c->d_layers + c->layer_off[0], c->d_layers + c->layer_off[1], c->first, c->last, alpha_raw, a);
+    if (rc) return rc;
+    c->mail_seq += 1;
+    HIPCHK(launch_compose_merkle(a, c->d_trees + c->tree_off[1], c->stream, prof_of(c), c->d_mailbox, c->mail_seq, c->hash));
+    return ZK_OK;
+}
+int do_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
+    FoldArgs a;
+    int rc = fold_args(c->dom, c->d_layers + c->layer_off[1 + round], c->d_layers + c->layer_off[2 + round], c->L - round, round, beta_raw, a);
+    if (rc) return rc;
+    c->mail_seq += 1;
+    HIPCHK(launch_fold_merkle(a, c->d_trees + c->tree_off[2 + round], c->stream, prof_of(c), c->d_mailbox, c->mail_seq, c->hash));
+    return ZK_OK;
+}
+
 // Waits for the root posted by the last do_merkle (polling host-coherent memory: no blit kernel, no
 // stream synchronisation on the commit -> challenge critical path).
 int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
@@ -410,15 +441,13 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     memcpy(c->info.roots[0], root, 32);
     uint32_t alpha[3];
     for (int i = 0; i < 3; ++i) alpha[i] = c->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
-    if ((rc = do_compose(c, alpha))) return rc;           // prover.rs:166-173
-    if ((rc = do_merkle(c, 1))) return rc;                // prover.rs:176
+    if ((rc = do_compose_commit(c, alpha))) return rc;    // prover.rs:166-176 (composition fused into the leaf hashing)
     if ((rc = read_root(c, 1, root))) return rc;
     ch.commit_hash(root);                                 // prover.rs:180
     memcpy(c->info.roots[1], root, 32);
     for (uint32_t r = 0; r < R; ++r) {                    // prover.rs:198-225
         uint32_t beta = c->info.beta_raw[r] = ch.get_u32();   // prover.rs:200
-        if ((rc = do_fold(c, r, beta))) return rc;        // prover.rs:201-211
-        if ((rc = do_merkle(c, 2 + r))) return rc;        // prover.rs:214
+        if ((rc = do_fold_commit(c, r, beta))) return rc;  // prover.rs:201-214 (fold fused into the leaf hashing)
         if ((rc = read_root(c, 2 + r, root))) return rc;
         ch.commit_hash(root);                             // prover.rs:224
         memcpy(c->info.roots[2 + r], root, 32);
