@@ -77,6 +77,10 @@ int zk_ctx_destroy(zk_ctx *ctx);
 double zk_ctx_setup_ms(const zk_ctx *ctx);
 size_t zk_ctx_device_bytes(const zk_ctx *ctx);
 int zk_ctx_sync(zk_ctx *ctx);
+/* Number of decommitment queries of later zk_prove* calls (1..64; default 1 = the reference,
+ * prover.rs:263).  With q > 1 the q raw indices are drawn in a row and each query's openings are
+ * committed in turn; q = 1 is byte-identical to the reference format. */
+int zk_ctx_set_queries(zk_ctx *ctx, uint32_t n_queries);
 /* Selects the Merkle hash of every later zk_merkle_commit / zk_prove* on this context. */
 int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
 /* The HIP stream every stage is enqueued on (hipStream_t). */
@@ -158,6 +162,9 @@ int zk_verify(const uint8_t *proof, size_t len, uint32_t log_n, uint32_t log_blo
               uint32_t public_last);
 int zk_verify_ex(const uint8_t *proof, size_t len, uint32_t log_n, uint32_t log_blowup,
                  uint32_t public_last, int hash_kind);
+/* General form: hash selector, q queries, and (state != NULL) the transcript replay of zk_verify_strict. */
+int zk_verify_queries(const uint8_t *proof, size_t len, const uint8_t *state, uint32_t log_n, uint32_t log_blowup,
+                      uint32_t public_last, int hash_kind, uint32_t n_queries);
 /* zk_verify plus a replay of the Fiat-Shamir channel over the proof bytes: every challenge must be
  * the one the transcript yields at that point and `state` (Proof.state, proof.rs:6, which the
  * reference stores but never checks) must be the final channel state.  SURVEY.md section 8f item 1. */
@@ -166,6 +173,7 @@ int zk_verify_strict(const uint8_t *proof, size_t len, const uint8_t state[32], 
 /* Proof::size (proof.rs:151-154). */
 size_t zk_proof_size(size_t data_len);
 size_t zk_proof_data_len(uint32_t log_n, uint32_t log_blowup);
+size_t zk_proof_data_len_queries(uint32_t log_n, uint32_t log_blowup, uint32_t n_queries);
 /* compute_root_from_path (merkle.rs:82-110), CPU. */
 int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t *path, size_t path_len,
                               uint8_t out[32]);

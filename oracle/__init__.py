@@ -77,6 +77,7 @@ def lib():
         L.orc_prove.restype = C.c_int
         L.orc_prove.argtypes = [u32, u32, u32, u32, C.c_int, vp, sz, C.POINTER(sz), vp, C.POINTER(_Debug)]
         L.orc_verify.restype = C.c_int; L.orc_verify.argtypes = [vp, sz, u32, u32, u32]
+        L.orc_set_queries.restype = None; L.orc_set_queries.argtypes = [u32]
         L.orc_proof_size.restype = sz; L.orc_proof_size.argtypes = [sz]
         L.orc_proof_data_len.restype = sz; L.orc_proof_data_len.argtypes = [u32, u32]
         _lib = L
@@ -280,6 +281,11 @@ def prove(log_n=10, log_b=3, a0=1, a1=3141592, mode=MODE_NTT, want_vectors=True)
 
 def verify(proof: bytes, log_n, log_b, public_last):
     return lib().orc_verify(proof, len(proof), log_n, log_b, public_last)
+
+
+def set_queries(q):
+    """Decommitment queries per proof (1 = the reference); affects prove, verify, proof_data_len."""
+    lib().orc_set_queries(int(q))
 
 
 def proof_size(data_len): return lib().orc_proof_size(data_len)

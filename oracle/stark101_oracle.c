@@ -776,11 +776,17 @@ static void commit_pair_paths(orc_channel *c, uint32_t v0, uint32_t v1, const ui
 /* prover.rs                                                                */
 /* ======================================================================== */
 
+/* Multi-query extension (the reference makes one query, prover.rs:263).  With
+ * q queries the prover draws q raw indices in a row (q x get_u32) and then commits the openings of
+ * each query in turn; q = 1 is byte-identical to the reference's format. */
+static uint32_t g_queries = 1;
+void orc_set_queries(uint32_t q) { g_queries = q ? (q > 64 ? 64 : q) : 1; }
+
 size_t orc_proof_data_len(uint32_t log_n, uint32_t log_b) {
     size_t L = log_n + log_b, R = log_n;
-    size_t len = 32 + 12 + 32 + R * 36 + 4 + 4 + 4 * (4 + 8 + 32 * L);
-    for (size_t i = 0; i < R; ++i) len += 8 + 2 * (8 + 32 * (L - i));
-    return len;
+    size_t per_query = 4 + 4 * (4 + 8 + 32 * L);
+    for (size_t i = 0; i < R; ++i) per_query += 8 + 2 * (8 + 32 * (L - i));
+    return 32 + 12 + 32 + R * 36 + 4 + g_queries * per_query;
 }
 /* proof.rs:151-154: size_of::<Proof>() = 32 (state) + 16 (Box<[u8]>) */
 size_t orc_proof_size(size_t data_len) { return 48 + data_len; }
@@ -792,11 +798,13 @@ static void decommit(orc_channel *ch, uint32_t log_n, uint32_t log_b, const uint
     size_t n = (size_t)1 << log_n, B = (size_t)1 << log_b, N = n << log_b, R = log_n;
     uint8_t *pa = (uint8_t *)malloc(32 * 64), *pb = (uint8_t *)malloc(32 * 64);
     commit_u32(ch, free_term);                                  /* prover.rs:254 */
-    uint32_t qraw = orc_channel_get_u32(ch);                    /* prover.rs:263 */
-    size_t x = (size_t)qraw % (N - 2 * B);
-    if (dbg) { dbg->free_term = free_term; dbg->query_raw = qraw; }
+    uint32_t qraws[64] = {0};
+    for (uint32_t k = 0; k < g_queries; ++k) qraws[k] = orc_channel_get_u32(ch);   /* prover.rs:263 (x q) */
+    if (dbg) { dbg->free_term = free_term; dbg->query_raw = qraws[0]; }
     const uint8_t *ftree = trees[0];
     size_t pl;
+    for (uint32_t k = 0; k < g_queries; ++k) {
+    size_t x = (size_t)qraws[k] % (N - 2 * B);
     pl = orc_merkle_trace(ftree, N, x, pa);         commit_val_path(ch, f_eval[x], pa, pl);         /* :266-274 */
     pl = orc_merkle_trace(ftree, N, x + B, pa);     commit_val_path(ch, f_eval[x + B], pa, pl);     /* :268-275 */
     pl = orc_merkle_trace(ftree, N, x + 2 * B, pa); commit_val_path(ch, f_eval[x + 2 * B], pa, pl); /* :270-276 */
@@ -806,6 +814,7 @@ static void decommit(orc_channel *ch, uint32_t log_n, uint32_t log_b, const uint
         size_t p0 = orc_merkle_trace(trees[1 + i], len, xi, pa);
         orc_merkle_trace(trees[1 + i], len, nx, pb);
         commit_pair_paths(ch, layers[i][xi], layers[i][nx], pa, pb, p0);
+    }
     }
     free(pa); free(pb);
 }
@@ -1033,7 +1042,10 @@ int orc_verify(const uint8_t *data, size_t len, uint32_t log_n, uint32_t log_b, 
     roots[0] = take(&r, 32); betas[0] = 0;
     for (size_t i = 0; i < R; ++i) { betas[i + 1] = take_u32(&r); roots[i + 1] = take(&r, 32); }
     uint32_t free_term = take_u32(&r);
-    uint32_t test_raw = take_u32(&r);
+    uint32_t test_raws[64];
+    for (uint32_t k = 0; k < g_queries; ++k) test_raws[k] = take_u32(&r);
+    for (uint32_t qk = 0; qk < g_queries; ++qk) {
+    uint32_t test_raw = test_raws[qk];
     uint32_t fv[4]; const uint8_t *fp[4]; size_t fpl[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) { fv[i] = take_u32(&r); fp[i] = take_path(&r, &fpl[i]); }
     uint32_t lx[40], lnx[40]; const uint8_t *lpx[40], *lpnx[40]; size_t lplx[40], lplnx[40];
@@ -1086,5 +1098,7 @@ int orc_verify(const uint8_t *data, size_t len, uint32_t log_n, uint32_t log_b, 
         orc_compute_root_from_path(lnx[k], (tp + size / 2) % size, lpnx[k], lplnx[k], root);
         if (memcmp(root, roots[k], 32)) return -(int)(400 + k);
     }
+    }
+    if (r.left != 0) return -8;
     return 0;
 }

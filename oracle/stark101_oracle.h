@@ -135,6 +135,8 @@ int orc_prove(uint32_t log_n, uint32_t log_b, uint32_t a0, uint32_t a1, int mode
 int orc_verify(const uint8_t *data, size_t len, uint32_t log_n, uint32_t log_b,
                uint32_t public_last);
 /* Proof::size (proof.rs:151-154): 48 + len on a 64-bit target. */
+/* Number of queries of the decommitment (default 1 = the reference, prover.rs:263); see the .c file. */
+void orc_set_queries(uint32_t q);
 size_t orc_proof_size(size_t data_len);
 size_t orc_proof_data_len(uint32_t log_n, uint32_t log_b);
 

@@ -150,3 +150,25 @@ def test_strict_verifier_replays_the_transcript(zk, orc):
     with pytest.raises(zk.ZkError) as e:
         zk.Proof(r.state, bytes(forged), 6, 2, r.public_last).verify(strict=True)
     assert "transcript" in str(e.value)
+
+
+def test_multi_query_proofs(zk, orc):
+    """q queries per proof; q = 1 is the reference's byte format."""
+    try:
+        base = orc.prove(6, 2, want_vectors=False)
+        for q in (2, 4):
+            orc.set_queries(q)
+            r = orc.prove(6, 2, want_vectors=False)
+            assert r.rc == 0 and len(r.proof) == orc.proof_data_len(6, 2)
+            assert r.proof[:len(base.proof) - (len(base.proof) - (32 + 12 + 32 + 6 * 36 + 4))] == base.proof[:32 + 12 + 32 + 6 * 36 + 4]
+            assert orc.verify(r.proof, 6, 2, r.public_last) == 0
+            p = zk.Proof(r.state, r.proof, 6, 2, r.public_last, queries=q)
+            p.verify(strict=True)
+            with pytest.raises(zk.ZkError):      # a q-query proof is not a (q-1)-query proof
+                zk.Proof(r.state, r.proof, 6, 2, r.public_last, queries=q - 1).verify()
+            bad = bytearray(r.proof)
+            bad[-100] ^= 1                       # tamper with the LAST query's openings
+            with pytest.raises(zk.ZkError):
+                zk.Proof(r.state, bytes(bad), 6, 2, r.public_last, queries=q).verify()
+    finally:
+        orc.set_queries(1)

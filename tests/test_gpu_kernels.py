@@ -222,3 +222,69 @@ def test_ntt_linearity_and_roundtrip_2e22(zk):
     s = ((x.astype(np.uint64) + y) % P).astype(np.uint32)
     assert np.array_equal(zk.ntt(s), ((fx.astype(np.uint64) + fy) % P).astype(np.uint32))
     assert np.array_equal(zk.ntt(fx, inverse=True), x)
+
+
+# ---- error behaviour at the boundary (the reference panics; the C ABI returns a status) ---------
+def test_stage_order_and_argument_errors(zk):
+    from zkstark_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    with zk.Context(6, 2) as ctx:
+        with pytest.raises(zk.ZkError) as e:          # compose before lde
+            ctx.compose([1, 2, 3])
+        assert e.value.code == -4
+        with pytest.raises(zk.ZkError) as e:          # prove without a trace
+            ctx.prove()
+        assert e.value.code == -4
+        with pytest.raises(zk.ZkError) as e:          # wrong trace length (prover.rs:60 needs n-1 points)
+            ctx.trace_upload(np.ones(64, dtype=np.uint32))
+        assert e.value.code == -1
+        with pytest.raises(zk.ZkError) as e:          # non-canonical residue
+            ctx.trace_upload(np.full(63, P, dtype=np.uint32))
+        assert e.value.code == -1
+        a = zk.trace_fibsq(63)
+        ctx.trace_upload(a)
+        with pytest.raises(zk.ZkError):               # out-of-range layer / fold round
+            ctx.layer_read(99)
+        with pytest.raises(zk.ZkError):
+            ctx.fri_fold(6, 1)
+        # caller buffer too small: ZK_ERR_BUFFER and the needed length is reported
+        buf = C.create_string_buffer(16)
+        st = C.create_string_buffer(32)
+        n = C.c_size_t()
+        rc = lib.zk_prove_resident(ctx._h, buf, 16, C.byref(n), st)
+        assert rc == -5 and n.value == lib.zk_proof_data_len(6, 2)
+        proof = ctx.prove()                           # the context is still usable afterwards
+        proof.verify(strict=True)
+
+
+def test_merkle_index_and_path_api(zk, orc):
+    """Index<usize> and trace() (merkle.rs:54-79) on a context-resident tree."""
+    a = zk.trace_fibsq(255)
+    with zk.Context(8, 2) as ctx:
+        ctx.trace_upload(a)
+        ctx.lde()
+        root = ctx.merkle_commit(0)
+        f = ctx.layer_read(0)
+        nodes = orc.merkle_build(f)
+        assert root == bytes(nodes[0])
+        for idx in (0, 1, 2, 511, 1023, 2046):
+            assert ctx.merkle_node(0, idx) == bytes(nodes[idx])
+        for leaf in (0, 7, 1023):
+            assert ctx.merkle_path(0, leaf) == [bytes(h) for h in orc.merkle_trace(nodes, leaf)]
+        with pytest.raises(zk.ZkError):
+            ctx.merkle_node(0, 2047)
+
+
+@pytest.mark.parametrize("q", [2, 7])
+def test_prover_multi_query(zk, orc, q):
+    """q decommitment queries: proof bytes equal to the oracle's, strict verifier accepts."""
+    try:
+        orc.set_queries(q)
+        want = orc.prove(10, 3, want_vectors=False)
+    finally:
+        orc.set_queries(1)
+    with zk.Context(10, 3, queries=q) as ctx:
+        proof = ctx.prove(zk.trace_fibsq(1023))
+    assert proof.data == want.proof and proof.state == want.state
+    proof.verify(strict=True)

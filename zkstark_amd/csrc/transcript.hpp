@@ -58,11 +58,13 @@ struct Channel {
     }
 };
 
-inline size_t proof_data_len(uint32_t log_n, uint32_t log_b) {
+// q = number of decommitment queries (1 = the reference's format, prover.rs:263; q > 1: SURVEY.md 8f
+// item 1 -- the q raw indices are drawn in a row, then each query's openings are committed in turn).
+inline size_t proof_data_len(uint32_t log_n, uint32_t log_b, uint32_t q = 1) {
     size_t L = log_n + log_b, R = log_n;
-    size_t len = 32 + 12 + 32 + R * 36 + 4 + 4 + 4 * (4 + 8 + 32 * L);
-    for (size_t i = 0; i < R; ++i) len += 8 + 2 * (8 + 32 * (L - i));
-    return len;
+    size_t per_query = 4 + 4 * (4 + 8 + 32 * L);
+    for (size_t i = 0; i < R; ++i) per_query += 8 + 2 * (8 + 32 * (L - i));
+    return 32 + 12 + 32 + R * 36 + 4 + (size_t)q * per_query;
 }
 
 // Merkle hash on the host (verifier): hash 0 = SHA-256 (merkle.rs:30-34, :42-45), 1 = field-native (fieldhash.hpp)
@@ -103,8 +105,8 @@ inline void compute_root_from_path(uint32_t element, size_t index, const uint8_t
 }
 
 // proof.rs:15-149 with the literals generalised.  Returns 0 or the negative index of the failed check.
-inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last, int hash = 0) {
-    if (log_n < 2 || log_b < 1 || log_n + log_b > 30) return -1;
+inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last, int hash = 0, uint32_t q = 1) {
+    if (log_n < 2 || log_b < 1 || log_n + log_b > 30 || q < 1 || q > 64) return -1;
     const size_t n = (size_t)1 << log_n, B = (size_t)1 << log_b, N = n << log_b, R = log_n, L = log_n + log_b;
     const uint8_t* p = data;
     size_t left = len;
@@ -132,7 +134,13 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
     const uint8_t* roots[40]; uint32_t betas[40];
     roots[0] = take(32); betas[0] = 0;
     for (size_t i = 0; i < R; ++i) { betas[i + 1] = take32(); roots[i + 1] = take(32); }
-    uint32_t free_term = take32(), test_raw = take32();
+    uint32_t free_term = take32();
+    uint32_t test_raws[64];
+    for (uint32_t k = 0; k < q; ++k) test_raws[k] = take32();
+    const uint32_t g = root_of_unity(log_n), h = root_of_unity((uint32_t)L);
+    auto fsub = [](uint32_t a, uint32_t b) { return sub(a, b); };
+    for (uint32_t qk = 0; qk < q; ++qk) {
+    const uint32_t test_raw = test_raws[qk];
     uint32_t fv[4]; const uint8_t* fp[4]; size_t fpl[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) { fv[i] = take32(); fp[i] = take_path(fpl[i]); }
     uint32_t lx[40], lnx[40]; const uint8_t *lpx[40], *lpnx[40]; size_t plx[40], plnx[40];
@@ -142,10 +150,8 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
     }
     if (bad) return -1;
     // proof.rs:49-60
-    const uint32_t g = root_of_unity(log_n), h = root_of_unity((uint32_t)L);
     const size_t tp = (size_t)test_raw % (N - 2 * B);
     const uint32_t x = mulmod(GEN_W, powmod(h, tp));
-    auto fsub = [](uint32_t a, uint32_t b) { return sub(a, b); };
     {   // proof.rs:63-77
         uint32_t f_x = fv[0] % P, f_gx = fv[1] % P, f_ggx = fv[2] % P;
         uint32_t gm1 = invmod(g), gm2 = mulmod(gm1, gm1), gm3 = mulmod(gm2, gm1);
@@ -183,6 +189,8 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
         compute_root_from_path(lnx[k], (tp + size / 2) % size, lpnx[k], plnx[k], root, hash);
         if (memcmp(root, roots[k], 32)) return -(int)(400 + k);
     }
+    }
+    if (left != 0) return -8;
     return 0;
 }
 
@@ -192,10 +200,10 @@ inline int verify_proof(const uint8_t* data, size_t len, uint32_t log_n, uint32_
 // order (prover.rs:85, :163-165, :180, :200, :224, :254, :263, :274-277, :288), checks that every
 // challenge equals the one the transcript yields at that point and that the final state matches.
 // Returns 0, or -(1000 + k) for the k-th challenge / -1999 for the state.
-inline int verify_transcript(const uint8_t* data, size_t len, const uint8_t state[32], uint32_t log_n, uint32_t log_b) {
+inline int verify_transcript(const uint8_t* data, size_t len, const uint8_t state[32], uint32_t log_n, uint32_t log_b, uint32_t q = 1) {
     if (log_n < 2 || log_b < 1 || log_n + log_b > 30) return -1;
     const size_t R = log_n, L = log_n + log_b;
-    if (len != proof_data_len(log_n, log_b)) return -1;
+    if (q < 1 || q > 64 || len != proof_data_len(log_n, log_b, q)) return -1;
     Channel ch;
     const uint8_t* p = data;
     int k = 0;
@@ -216,9 +224,11 @@ inline int verify_transcript(const uint8_t* data, size_t len, const uint8_t stat
         commit(32);                                         // layer root
     }
     commit(4);                                              // free term
-    if (!challenge()) return -(1000 + k);                   // query
-    for (int i = 0; i < 4; ++i) commit(4 + 8 + 32 * L);
-    for (size_t i = 0; i < R; ++i) commit(8 + 2 * (8 + 32 * (L - i)));
+    for (uint32_t j = 0; j < q; ++j) if (!challenge()) return -(1000 + k);   // queries
+    for (uint32_t j = 0; j < q; ++j) {
+        for (int i = 0; i < 4; ++i) commit(4 + 8 + 32 * L);
+        for (size_t i = 0; i < R; ++i) commit(8 + 2 * (8 + 32 * (L - i)));
+    }
     if (memcmp(ch.state, state, 32)) return -1999;
     return 0;
 }

@@ -46,6 +46,7 @@ int fail(int code, const char* fmt, ...) {
 // ---- transform plan ----------------------------------------------------------
 // The size-2^log_m transform is split into radix-2^bits[d] passes, d = 0 slowest
 // storage digit.  DIF (inverse) runs d = 0 .. nd-1, DIT (forward) nd-1 .. 0.
+constexpr uint32_t kMaxQueries = 64;
 constexpr uint32_t kTileLog = 13;      // 8192 words = 32 KiB per workgroup tile
 constexpr uint32_t kMaxRadixLog = 8;
 
@@ -309,6 +310,7 @@ struct zk_ctx {
     uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: [seq, -, root words 0..7]
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
     uint32_t mail_seq = 0;
+    uint32_t queries = 1;               // decommitment queries (1 = the reference, prover.rs:263)
     int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
     size_t gather_cap = 0;
     size_t device_bytes = 0;
@@ -460,10 +462,12 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
             return fail(ZK_ERR_CHECK, "last FRI layer is not constant (prover.rs:238): trace does not satisfy the constraints");
     uint32_t free_term = c->info.free_term = c->h_small[0];
     ch.commit_u32(free_term);                             // prover.rs:254
-    uint32_t qraw = c->info.query_raw = ch.get_u32();     // prover.rs:263
-    const size_t x = (size_t)qraw % (N - 2 * B);
+    const uint32_t Q = c->queries;
+    uint32_t qraws[64];
+    for (uint32_t k = 0; k < Q; ++k) qraws[k] = ch.get_u32();   // prover.rs:263 (x Q)
+    c->info.query_raw = qraws[0];
 
-    // decommit (prover.rs:266-289): one gather for the values, one for the path digests
+    // decommit (prover.rs:266-289): one gather for the values, one for the path digests, all queries
     std::vector<uint64_t> voff, doff;
     std::vector<size_t> nodes;
     auto add_path = [&](uint32_t tree, size_t m, size_t leaf) {
@@ -471,14 +475,17 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
         path_nodes(m, leaf, nodes);
         for (size_t nd : nodes) doff.push_back((uint64_t)c->tree_off[tree] + (uint64_t)nd * 8);
     };
-    voff.push_back(c->layer_off[0] + x);         add_path(0, N, x);
-    voff.push_back(c->layer_off[0] + x + B);     add_path(0, N, x + B);
-    voff.push_back(c->layer_off[0] + x + 2 * B); add_path(0, N, x + 2 * B);
-    voff.push_back(c->layer_off[1] + x);         add_path(1, N, x);
-    for (uint32_t i = 0; i < R; ++i) {
-        size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
-        voff.push_back(c->layer_off[1 + i] + xi); add_path(1 + i, len, xi);
-        voff.push_back(c->layer_off[1 + i] + nx); add_path(1 + i, len, nx);
+    for (uint32_t k = 0; k < Q; ++k) {
+        const size_t x = (size_t)qraws[k] % (N - 2 * B);
+        voff.push_back(c->layer_off[0] + x);         add_path(0, N, x);
+        voff.push_back(c->layer_off[0] + x + B);     add_path(0, N, x + B);
+        voff.push_back(c->layer_off[0] + x + 2 * B); add_path(0, N, x + 2 * B);
+        voff.push_back(c->layer_off[1] + x);         add_path(1, N, x);
+        for (uint32_t i = 0; i < R; ++i) {
+            size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
+            voff.push_back(c->layer_off[1 + i] + xi); add_path(1 + i, len, xi);
+            voff.push_back(c->layer_off[1 + i] + nx); add_path(1 + i, len, nx);
+        }
     }
     const size_t nv = voff.size(), ndg = doff.size();
     if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
@@ -496,14 +503,16 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     const uint32_t* vals = c->h_gather_out;
     const size_t Lp = c->L;
     size_t dpos = 0;
-    for (int k = 0; k < 4; ++k) {                         // prover.rs:274-277
-        ch.commit_val_path(vals[k], dig.data() + 32 * dpos, Lp);
-        dpos += Lp;
-    }
-    for (uint32_t i = 0; i < R; ++i) {                    // prover.rs:280-289
-        size_t pl = Lp - i;
-        ch.commit_pair_paths(vals[4 + 2 * i], vals[5 + 2 * i], dig.data() + 32 * dpos, dig.data() + 32 * (dpos + pl), pl);
-        dpos += 2 * pl;
+    for (uint32_t q = 0; q < Q; ++q, vals += 4 + 2 * R) {
+        for (int k = 0; k < 4; ++k) {                         // prover.rs:274-277
+            ch.commit_val_path(vals[k], dig.data() + 32 * dpos, Lp);
+            dpos += Lp;
+        }
+        for (uint32_t i = 0; i < R; ++i) {                    // prover.rs:280-289
+            size_t pl = Lp - i;
+            ch.commit_pair_paths(vals[4 + 2 * i], vals[5 + 2 * i], dig.data() + 32 * dpos, dig.data() + 32 * (dpos + pl), pl);
+            dpos += 2 * pl;
+        }
     }
     proof = std::move(ch.data);                           // channel.rs:34-36
     memcpy(state_out, ch.state, 32);
@@ -576,7 +585,7 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     if ((rc = dmalloc(c, &c->d_coef, 2 * c->n * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_layers, layer_words * 4))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_trees, tree_words * 4))) return bail(rc);
-    c->gather_cap = (size_t)(4 + 2 * c->R) * (c->L + 1) + 64;
+    c->gather_cap = (size_t)kMaxQueries * (4 + 2 * c->R) * (c->L + 1) + 64;
     if ((rc = dmalloc(c, &c->d_gather_off, c->gather_cap * 8))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_gather_out, c->gather_cap * 32))) return bail(rc);
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8));
@@ -621,6 +630,13 @@ int zk_ctx_sync(zk_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
+int zk_ctx_set_queries(zk_ctx* c, uint32_t n_queries) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    if (n_queries < 1 || n_queries > kMaxQueries) return fail(ZK_ERR_INVALID, "zk_ctx_set_queries: need 1 <= n_queries <= %u", kMaxQueries);
+    c->queries = n_queries;
+    return ZK_OK;
+}
+
 int zk_ctx_set_hash(zk_ctx* c, int hash_kind) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
     if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_ctx_set_hash: unknown hash %d", hash_kind);
@@ -781,6 +797,18 @@ int zk_verify_ex(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_
 int zk_verify(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last) {
     return zk_verify_ex(proof, len, log_n, log_b, public_last, ZK_HASH_SHA256);
 }
+int zk_verify_queries(const uint8_t* proof, size_t len, const uint8_t* state, uint32_t log_n, uint32_t log_b, uint32_t public_last,
+                      int hash_kind, uint32_t n_queries) {
+    if (!proof) return fail(ZK_ERR_INVALID, "zk_verify_queries: null proof");
+    if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_verify_queries: unknown hash %d", hash_kind);
+    if (state) {
+        int rc = verify_transcript(proof, len, state, log_n, log_b, n_queries);
+        if (rc) return fail(ZK_ERR_VERIFY, "transcript replay failed at check %d", rc);
+    }
+    int rc = verify_proof(proof, len, log_n, log_b, public_last, hash_kind, n_queries);
+    if (rc) return fail(ZK_ERR_VERIFY, "proof rejected at check %d (proof.rs:15-149)", rc);
+    return ZK_OK;
+}
 
 int zk_verify_strict(const uint8_t* proof, size_t len, const uint8_t state[32], uint32_t log_n, uint32_t log_b, uint32_t public_last) {
     if (!proof || !state) return fail(ZK_ERR_INVALID, "zk_verify_strict: null argument");
@@ -791,6 +819,7 @@ int zk_verify_strict(const uint8_t* proof, size_t len, const uint8_t state[32], 
 
 size_t zk_proof_size(size_t data_len) { return 48 + data_len; }   // proof.rs:151-154: size_of::<Proof>() = 32 + 16
 size_t zk_proof_data_len(uint32_t log_n, uint32_t log_b) { return proof_data_len(log_n, log_b); }
+size_t zk_proof_data_len_queries(uint32_t log_n, uint32_t log_b, uint32_t n_queries) { return proof_data_len(log_n, log_b, n_queries); }
 
 int zk_compute_root_from_path_ex(uint32_t element, size_t index, const uint8_t* path, size_t path_len, uint8_t out[32], int hash_kind) {
     if ((!path && path_len) || !out || path_len > 62 || (hash_kind != 0 && hash_kind != 1))

@@ -108,20 +108,16 @@ class Channel:
 class Proof:
     """proof.rs:5-154.  verify() raises ZkError where the reference panics."""
 
-    def __init__(self, state, data, log_n=10, log_blowup=3, public_last=2338775057, hash="sha256"):   # proof.rs:11
+    def __init__(self, state, data, log_n=10, log_blowup=3, public_last=2338775057, hash="sha256", queries=1):   # proof.rs:11
         self.state, self.data = bytes(state), bytes(data)
         self.log_n, self.log_blowup, self.public_last = log_n, log_blowup, public_last
-        self.hash = hash
+        self.hash, self.queries = hash, queries
 
     def verify(self, strict=False):                  # proof.rs:15
         """strict=True also replays the channel: challenges must come from the transcript and `state`
         must be its final state (the reference trusts the proof for both, proof.rs:22-37)."""
-        if strict and self.hash == "sha256":
-            check(_lib.load().zk_verify_strict(self.data, len(self.data), self.state, self.log_n, self.log_blowup,
-                                               self.public_last))
-        else:
-            check(_lib.load().zk_verify_ex(self.data, len(self.data), self.log_n, self.log_blowup, self.public_last,
-                                           HASHES[self.hash]))
+        check(_lib.load().zk_verify_queries(self.data, len(self.data), self.state if strict else None, self.log_n,
+                                            self.log_blowup, self.public_last, HASHES[self.hash], self.queries))
 
     def size(self):                                  # proof.rs:151
         return _lib.load().zk_proof_size(len(self.data))
@@ -187,14 +183,16 @@ def lde(trace, log_n, log_blowup, device=0):
 class Context:
     """Device-resident prover state for one (log_n, log_blowup): zk_ctx."""
 
-    def __init__(self, log_n=10, log_blowup=3, device=0, hash="sha256"):
-        self.log_n, self.log_blowup, self.device, self.hash = log_n, log_blowup, device, hash
+    def __init__(self, log_n=10, log_blowup=3, device=0, hash="sha256", queries=1):
+        self.log_n, self.log_blowup, self.device, self.hash, self.queries = log_n, log_blowup, device, hash, queries
         self.n, self.B = 1 << log_n, 1 << log_blowup
         self.N, self.rounds = self.n * self.B, log_n
         self._h = C.c_void_p()
         check(_lib.load().zk_ctx_create(device, log_n, log_blowup, C.byref(self._h)))
         if hash != "sha256":
             check(_lib.load().zk_ctx_set_hash(self._h, HASHES[hash]))
+        if queries != 1:
+            check(_lib.load().zk_ctx_set_queries(self._h, queries))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -272,7 +270,7 @@ class Context:
 
     def prove(self, trace=None):
         """generate_proof as one C call (C++ host prover). trace=None: already uploaded."""
-        cap = _lib.load().zk_proof_data_len(self.log_n, self.log_blowup)
+        cap = _lib.load().zk_proof_data_len_queries(self.log_n, self.log_blowup, self.queries)
         buf = C.create_string_buffer(cap)
         st = C.create_string_buffer(32)
         n = C.c_size_t()
@@ -282,7 +280,7 @@ class Context:
             t = _u32arr(trace)
             check(_lib.load().zk_prove(self._h, _ptr(t), len(t), buf, cap, C.byref(n), st))
         info = self.last_transcript()
-        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, info.public_last, self.hash)
+        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, info.public_last, self.hash, self.queries)
 
     def last_transcript(self):
         info = _lib.TranscriptInfo()
