@@ -98,16 +98,20 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     log_n, log_b = args.log_n, args.log_blowup
     N = 1 << (log_n + log_b)
 
-    if world > 1:
+    # ZK_BENCH_FORCE_SHARDED=1: run the N > 1 code path (sharded prover + RCCL collectives) with one rank
+    force_sharded = os.environ.get("ZK_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         from zkstark_amd import sharded
-        result = sharded.bench(args, rank, local_rank, world, barrier, staged=staged)
+        if world == 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        result = sharded.bench(args, rank, local_rank, world, barrier, staged=staged, force=force_sharded)
         log_n = result["log_n"]
         N = 1 << (log_n + log_b)
     else:
@@ -159,7 +163,7 @@ def main():
         ctx.close()
 
     dt = result["dt"]
-    if world > 1:
+    if world > 1 or force_sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -215,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.hash == "sha256":
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

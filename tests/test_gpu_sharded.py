@@ -103,3 +103,40 @@ def test_shard_domain_primitives_match_definition(zk, orc, log_n, log_b, rank_ex
         assert np.array_equal(hb.to_host(nh), ob.to_host(no)), rnd
         cur_h, cur_o = nh, no
     hb.close()
+
+
+def _nccl_worker(port, log_n, log_b, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import zkstark_amd as zk
+        from zkstark_amd import sharded
+        be = sharded.HipBackend(0)
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(force=True), be, min_chunk_log=6)
+        sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        proof = sp.prove()
+        dist.barrier()
+        q.put((proof.data, proof.state))
+        sp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_collectives_over_rccl_single_rank(orc):
+    """The exact torch.distributed calls of the N > 1 path (all_to_all_single, all_gather_into_tensor on
+    int32 device tensors, barrier) over the nccl backend = RCCL, with the one rank a one-GPU box allows."""
+    import torch.multiprocessing as mp
+    want = orc.prove(12, 3, want_vectors=False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, 12, 3, q))
+    p.start()
+    data, state = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert data == want.proof and state == want.state

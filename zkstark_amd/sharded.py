@@ -78,9 +78,10 @@ class Comm:
     """The three collectives the path needs, over torch.distributed.  `staged` moves device tensors
     through host memory (gloo); with the nccl backend (RCCL) tensors are exchanged in place."""
 
-    def __init__(self, group=None, staged=False):
+    def __init__(self, group=None, staged=False, force=False):
         import torch.distributed as dist
         self.dist, self.group, self.staged = dist, group, staged
+        self.force = force          # run the collectives even with one rank (exercises RCCL on a one-GPU box)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -107,7 +108,7 @@ class Comm:
 
 class LocalComm:
     """world = 1 (no process group): lets the sharded code path run in a single process."""
-    rank, world = 0, 1
+    rank, world, force = 0, 1, False
 
 
 class HipBackend:
@@ -251,14 +252,14 @@ class ShardedProver:
         loc = self._layer(lid)
         cnt = loc.numel()
         recv, block = self.recv[:cnt], self.block[:cnt]
-        if G > 1:
+        if G > 1 or self.comm.force:
             self.comm.all_to_all(loc, recv)                       # chunk q: rank q's j in my block
             be.interleave(recv, block, lg, m_log - 2 * lg)        # block[u*G + q] = recv[q][u]
         else:
             block = loc
         nodes = self._tree(lid)
         be.merkle(block, m_log - lg, nodes)
-        if G > 1:
+        if G > 1 or self.comm.force:
             self.comm.all_gather(nodes[:8], self.subroot_all)
             words = be.to_host(self.subroot_all).reshape(G, 8)
         else:
@@ -298,7 +299,7 @@ class ShardedProver:
                 cnt = (1 << (m_log - 1)) // G
                 piece = self.recv[:cnt]
                 be.fold(self.dom_loc, src, piece, m_log - lg, rho, beta)
-                if G > 1:
+                if G > 1 or self.comm.force:
                     gathered = self.gbuf[:cnt * G]
                     self.comm.all_gather(piece, gathered)
                     be.interleave(gathered, self._layer(dst_id), lg, m_log - 1 - lg)
@@ -361,7 +362,7 @@ class ShardedProver:
         vals = be.gather(self.layers, voff, 1)
         digs = be.gather(self.trees, doff, 8)
         nv, nd = len(voff), len(doff)
-        if G > 1:
+        if G > 1 or self.comm.force:
             import torch
             mine = torch.cat([vals, digs])
             allc = be.empty(mine.numel() * G)
@@ -385,12 +386,12 @@ class ShardedProver:
         self.be.close()
 
 
-def bench(args, rank, local_rank, world, barrier, staged=False):
+def bench(args, rank, local_rank, world, barrier, staged=False, force=False):
     """bench.py leg for N > 1: one proof over `world` GPUs at domain 2^(log_n + log_blowup) * world
     (weak scaling: per-GPU work equals the single-GPU workload)."""
     lg = world.bit_length() - 1
     log_n = args.log_n + lg
-    comm = Comm(staged=staged)
+    comm = Comm(staged=staged, force=force)
     be = HipBackend(local_rank)
     t0 = time.perf_counter()
     sp = ShardedProver(log_n, args.log_blowup, comm, be)
