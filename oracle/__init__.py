@@ -17,13 +17,15 @@ MODE_NTT, MODE_NAIVE = 0, 1
 
 
 def build(force=False):
-    """Compile liboracle.so with gcc (seconds)."""
-    src = os.path.join(_HERE, "stark101_oracle.c")
-    hdr = os.path.join(_HERE, "stark101_oracle.h")
-    if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    """Compile liboracle.so with gcc (seconds).  An existing library is used as is unless force=True
+    (several test workers may import at once; a snapshot copy does not preserve mtimes)."""
+    if not force and os.path.exists(_LIB_PATH):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not os.path.exists(_LIB_PATH):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -115,7 +115,7 @@ def load():
     if _lib is not None:
         return _lib
     try:
-        _build.build()
+        _build.build(if_missing_only=True)   # an existing library is used as is (python -m zkstark_amd.build rebuilds)
     except Exception as e:  # no hipcc on this box: use the prebuilt .so that travelled with the repo
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"libzkstark_amd.so is missing and cannot be built: {e}") from e

@@ -24,17 +24,30 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, if_missing_only=False):
+    """force: always rebuild.  if_missing_only: never rebuild an existing library (what import-time
+    loading uses: several ranks may import at once, and a snapshot copy does not preserve mtimes)."""
+    if not force and os.path.exists(LIB) and (if_missing_only or not _stale()):
         return LIB
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:           # one builder at a time across processes
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB) and (if_missing_only or not _stale()):
+            return LIB
+        return _build(verbose)
+
+
+def _build(verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libzkstark_amd.so")
+    tmp = LIB + f".tmp{os.getpid()}"
     cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)                              # atomic: a concurrent loader never sees a partial file
     return LIB
 
 

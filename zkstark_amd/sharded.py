@@ -370,17 +370,25 @@ class ShardedProver:
             allh = be.to_host(allc).reshape(G, nv + 8 * nd)
         else:
             allh = np.concatenate([be.to_host(vals), be.to_host(digs)]).reshape(1, nv + 8 * nd)
-        V = [int(allh[me if o == -1 else o, k]) for k, (o, _) in enumerate(val_items)]
-        D = [words_to_bytes(allh[me if o == -1 else o, nv + 8 * k: nv + 8 * k + 8]) for k, (o, _) in enumerate(dig_items)]
+        # pick every slot from its owner's row (vectorised), digests straight to SHA-256 byte order
+        vo = np.array([me if o == -1 else o for o, _ in val_items], dtype=np.int64)
+        V = allh[vo, np.arange(nv)]
+        do = np.array([me if o == -1 else o for o, _ in dig_items], dtype=np.int64)
+        cols = nv + 8 * np.arange(nd)[:, None] + np.arange(8)[None, :]
+        dbytes = allh[do[:, None], cols].astype(">u4").tobytes()       # nd * 32 bytes
         dpos = 0
-        paths = []
+        blobs = []
         for nloc, top_path in openings:
-            paths.append(D[dpos:dpos + nloc] + top_path)
+            plen = nloc + len(top_path)
+            blobs.append(struct.pack("<Q", plen) + dbytes[32 * dpos:32 * (dpos + nloc)] + b"".join(top_path))
             dpos += nloc
-        for k in range(4):
-            ch.commit((V[k], paths[k]))                                               # prover.rs:274-277
-        for i in range(R):
-            ch.commit((V[4 + 2 * i], V[5 + 2 * i], paths[4 + 2 * i], paths[5 + 2 * i]))   # prover.rs:288
+        lib, h = _lib.load(), ch._h
+        for k in range(4):                                                            # prover.rs:274-277
+            b = struct.pack("<I", int(V[k])) + blobs[k]
+            check(lib.zk_channel_commit(h, b, len(b)))
+        for i in range(R):                                                            # prover.rs:288
+            b = struct.pack("<II", int(V[4 + 2 * i]), int(V[5 + 2 * i])) + blobs[4 + 2 * i] + blobs[5 + 2 * i]
+            check(lib.zk_channel_commit(h, b, len(b)))
 
     def close(self):
         self.be.close()
