@@ -13,8 +13,9 @@ shift w h^r.  The only exchange step is the commitment: Merkle leaves are in nat
 per committed layer ONE all-to-all of the 4-byte values turns the cyclic layout into contiguous
 blocks of m/G leaves, each rank hashes its subtree, the G subtree roots (32 B each) are
 all-gathered and the top log2(G) levels are hashed on the host by every rank.  Once a layer has
-fewer than 2^min_chunk_log leaves per (rank, peer) chunk it is all-gathered once and the
-remaining small layers are folded and committed redundantly on every rank.  The transcript
+fewer than 2^min_chunk_log leaves per (rank, peer) chunk (default 2^14: below that the two
+collectives of a commitment cost more than hashing the whole layer redundantly) it is
+all-gathered once and the remaining small layers are folded and committed on every rank.  The transcript
 (channel.rs) runs identically on every rank, so challenges are never broadcast.  No all-reduce.
 
 Collectives per proof: (number of sharded layers + 1) all-to-alls, as many 256-byte
@@ -177,7 +178,7 @@ class HipBackend:
 class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
 
-    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=10):
+    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=14):
         self.log_n, self.log_b, self.comm, self.be = log_n, log_blowup, comm, backend
         G = comm.world
         self.G, self.rank = G, comm.rank
