@@ -139,7 +139,7 @@ enum zk_kernel_class {
     ZK_K_NTT = 0,           /* ntt_pass_kernel (iNTT / LDE passes) */
     ZK_K_MERKLE_LEAF = 1,   /* merkle_subtree_kernel<leaf>: leaf hashes + k inner levels */
     ZK_K_MERKLE_INNER = 2,  /* merkle_subtree_kernel<inner> */
-    ZK_K_MERKLE_TOP = 3,    /* merkle_top_kernel */
+    ZK_K_MERKLE_TOP = 3,    /* merkle_wg_kernel: the latency-bound levels, workgroup-local */
     ZK_K_COMPOSE = 4,
     ZK_K_FOLD = 5,
     ZK_K_GATHER = 6,

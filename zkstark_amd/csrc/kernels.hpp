@@ -16,7 +16,7 @@ enum KernelClass : int {
     K_NTT = 0,
     K_MERKLE_LEAF = 1,    // merkle_subtree_kernel<true>: leaf hashes + k inner levels
     K_MERKLE_INNER = 2,   // merkle_subtree_kernel<false>
-    K_MERKLE_TOP = 3,     // merkle_top_kernel
+    K_MERKLE_TOP = 3,     // merkle_wg_kernel (latency phase: workgroup-local levels)
     K_COMPOSE = 4,
     K_FOLD = 5,
     K_GATHER = 6,

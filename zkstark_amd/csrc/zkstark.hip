@@ -429,6 +429,14 @@ void path_nodes(size_t m, size_t leaf, std::vector<size_t>& out) {
 
 int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]) {
     if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_prove_resident: no trace uploaded");
+    static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[zk timing] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count());
+        T0 = t;
+    };
     const uint32_t R = c->R;
     const size_t B = c->B, N = c->N;
     Channel ch;                                          // main.rs:19
@@ -454,6 +462,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
         ch.commit_hash(root);                             // prover.rs:224
         memcpy(c->info.roots[2 + r], root, 32);
     }
+    lap("lde .. last root");
     // last layer: B evaluations of a degree-0 polynomial (prover.rs:238, :251); free term prover.rs:254
     HIPCHK(hipMemcpyAsync(c->h_small, c->d_layers + c->layer_off[1 + R], B * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -497,7 +506,9 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
         HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream, prof_of(c)));
         HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    lap("free term + gather enqueue");
     HIPCHK(hipStreamSynchronize(c->stream));
+    lap("gather wait");
     std::vector<uint8_t> dig(ndg * 32);
     for (size_t i = 0; i < ndg; ++i) digest_words_to_bytes(c->h_gather_out + nv + 8 * i, dig.data() + 32 * i);
     const uint32_t* vals = c->h_gather_out;
@@ -514,6 +525,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
             dpos += 2 * pl;
         }
     }
+    lap("decommit host hashing");
     proof = std::move(ch.data);                           // channel.rs:34-36
     memcpy(state_out, ch.state, 32);
     return ZK_OK;
