@@ -38,9 +38,14 @@ def main():
         wb = sum(W.get(k, [])) * 1024 / max(nw, 1)
         res["kernels"][k] = {"launches_seen": nf, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                              "hbm_bytes_per_launch": fb + wb}
-    leaf = [v for k, v in res["kernels"].items() if "merkle_subtree_kernel<true>" in k]
-    if leaf:
-        res["merkle_leaf_bytes_per_launch"] = leaf[0]["hbm_bytes_per_launch"]
+    # the dominant kernel class of bench.py: every leaf-mode instantiation of merkle_subtree_kernel
+    # (plain, fused-fold and fused-compose sources), averaged over all of their launches
+    leaf = [k for k in set(F) | set(W) if "merkle_subtree_kernel<" in k and ", true," in k]
+    nl = sum(len(W.get(k, [])) for k in leaf)
+    if nl:
+        tot = sum(2.0 * sum(F.get(k, [])) + sum(W.get(k, [])) for k in leaf) * 1024
+        res["merkle_leaf_bytes_per_launch"] = tot / nl
+        res["merkle_leaf_launches_seen"] = nl
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(f"{v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  {k[:90]}")
