@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--log-blowup", type=int, default=3)
     ap.add_argument("--hash", choices=("sha256", "field"), default="sha256",
                     help="Merkle hash: the reference's SHA-256 (the benchmark), or the field-native hash of configs[4]")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (configs[1] and proofs in flight): profiling runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="also report throughput with this many proofs in flight (1 = skip)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=21, help="oracle sample: domain 2^(this+blowup)")
@@ -139,7 +141,7 @@ def main():
                   "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
                   "units": N * args.steps, "parallelism": "single-gpu"}
         # secondary figure: BASELINE.json configs[1], domain 2^20 LDE + Merkle commit (trace resident -> root on host)
-        if args.hash == "sha256":
+        if args.hash == "sha256" and not args.no_secondary:
             with zk.Context(17, 3, device=local_rank) as c2:
                 c2.trace_upload(zk.trace_fibsq((1 << 17) - 1))
                 for _ in range(3):
@@ -150,7 +152,7 @@ def main():
                 dt2 = (time.perf_counter() - t0) / 20
             result["lde_commit_2e20"] = {"workload": "configs[1]: domain 2^20 LDE + Merkle commit", "us": dt2 * 1e6,
                                          "value": (1 << 20) / dt2, "unit": "field-elements/s"}
-        if args.in_flight > 1:
+        if args.in_flight > 1 and not args.no_secondary:
             # secondary figure: several independent proofs in flight on one GPU (one context, stream and
             # host thread each), so one proof's latency-bound tree tops overlap another's hashing
             import threading
