@@ -47,6 +47,7 @@ enum zk_status {
 };
 
 typedef struct zk_ctx zk_ctx;
+typedef struct zk_channel zk_channel;   /* Channel (channel.rs:6-37), see below */
 
 /* Merkle hash.  SHA-256 is the reference's (merkle.rs:1-2) and the default everywhere.  The
  * field-native hash (a Poseidon2-style permutation over GF(P), csrc/fieldhash.hpp) is the build's
@@ -182,7 +183,6 @@ int zk_compute_root_from_path_ex(uint32_t element, size_t index, const uint8_t *
                                  uint8_t out[32], int hash_kind);
 
 /* ---- Channel (channel.rs:6-37), host only ------------------------------------ */
-typedef struct zk_channel zk_channel;
 int zk_channel_new(zk_channel **out);                                        /* channel.rs:12 */
 int zk_channel_free(zk_channel *ch);
 int zk_channel_commit(zk_channel *ch, const uint8_t *bytes, size_t n);       /* channel.rs:19 */
@@ -190,6 +190,19 @@ int zk_channel_get_u32(zk_channel *ch, uint32_t *out);                       /* 
 int zk_channel_state(const zk_channel *ch, uint8_t out[32]);
 size_t zk_channel_data_len(const zk_channel *ch);
 int zk_channel_data(const zk_channel *ch, uint8_t *out, size_t cap);         /* channel.rs:34 */
+
+/* FRI tail: the last layers of a proof whose earlier layers live elsewhere (one proof sharded over
+ * several GPUs hands over once a layer is small enough to be replicated).  Layer rho0 of a
+ * (log_n, log_blowup) proof is layer 0 of a domain with log_n_tail = log_n - rho0 and shift
+ * w^(2^rho0).  zk_tail_run copies the handed-over layer (2^(log_n_tail+log_blowup) words at d_layer0,
+ * produced on src_stream), commits it, then runs the remaining log_n_tail rounds of prover.rs:198-225
+ * (fused fold + commit) on the caller's channel: betas_out[log_n_tail], roots_out[(log_n_tail+1)*32].
+ * zk_tail_open gathers the openings of prover.rs:280-289 for the tail layers.  Destroy with
+ * zk_ctx_destroy. */
+int zk_tail_create(int device, uint32_t log_n_tail, uint32_t log_blowup, uint32_t shift, zk_ctx **out);
+int zk_tail_run(zk_ctx *tail, const uint32_t *d_layer0, void *src_stream, zk_channel *ch, int hash_kind,
+                uint32_t *betas_out, uint8_t *roots_out, uint32_t *free_term_out);
+int zk_tail_open(zk_ctx *tail, size_t x, uint32_t *vals_out, uint8_t *paths_out);
 
 /* Timing of the zk_dev_* launches (process-wide; same classes and semantics as
  * zk_ctx_set_profiling / zk_kernel_stats). */

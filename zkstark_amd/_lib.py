@@ -100,6 +100,9 @@ SYMBOLS = {
     "zk_dev_fri_fold": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "zk_dev_interleave": (_int, [_vp, _vp, _u32, _u32, _vp]),
     "zk_dev_gather": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "zk_tail_create": (_int, [_int, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "zk_tail_run": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_u32)]),
+    "zk_tail_open": (_int, [_vp, _sz, _vp, _vp]),
     "zk_dev_set_profiling": (_int, [_u32]),
     "zk_dev_kernel_stats": (_int, [_vp, _sz, _int]),
     "zk_dev_merkle_build": (_int, [_vp, _u32, _vp, _vp]),

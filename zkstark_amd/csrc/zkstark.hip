@@ -310,6 +310,7 @@ struct zk_ctx {
     uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: [seq, -, root words 0..7]
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
     uint32_t mail_seq = 0;
+    bool tail = false;                  // FRI-tail context (zk_tail_*): no trace / LDE / composition
     uint32_t queries = 1;               // decommitment queries (1 = the reference, prover.rs:263)
     int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
     size_t gather_cap = 0;
@@ -551,6 +552,8 @@ uint32_t zk_field_from_u32(uint32_t v) { return v % P; }
 uint32_t zk_field_generator(void) { return GEN_W; }
 uint32_t zk_field_root_of_unity(uint32_t log_order) { return log_order > 30 ? 0 : root_of_unity(log_order); }
 
+static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool tail, zk_ctx** out);
+
 int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     if (!out) return fail(ZK_ERR_INVALID, "zk_ctx_create: out is null");
     *out = nullptr;
@@ -558,6 +561,11 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
         return fail(ZK_ERR_INVALID, "zk_ctx_create: need 2 <= log_n, 1 <= log_blowup <= 5, log_n + log_blowup <= 30 (got %u, %u)", log_n, log_b);
     if (log_n == 3)   // g^4 = -1: the leading terms of f(gx)^2 + f(x)^2 cancel and deg c2 < n-1
         return fail(ZK_ERR_INVALID, "zk_ctx_create: n = 8 is degenerate for the Fibonacci-square constraints (the degree asserts of prover.rs:156/:169 would fail)");
+    return ctx_make(device, log_n, log_b, GEN_W, false, out);
+}
+
+// tail = true: a context that only runs the FRI phase (layers 1.., fold-only domain with an arbitrary shift)
+static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool tail, zk_ctx** out) {
     auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(device));
     zk_ctx* c = new (std::nothrow) zk_ctx();
@@ -577,7 +585,8 @@ int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
         }                                                                                     \
     } while (0)
     HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if ((rc = dom_make(device, log_n, log_b, GEN_W, false, c->stream, &c->dom))) return bail(rc);
+    if ((rc = dom_make(device, log_n, log_b, shift, tail, c->stream, &c->dom))) return bail(rc);
+    c->tail = tail;
     c->device_bytes += c->dom->device_bytes;
     // layers: 0 = f_eval (N), 1 + r = FRI layer r (N >> r), r = 0 .. R
     size_t off = 0;
@@ -847,6 +856,84 @@ int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t* pat
 struct zk_channel {
     Channel ch;
 };
+
+// ---- FRI tail -----------------------------------------------------------------------
+// The last FRI layers of a proof whose earlier layers live elsewhere (the sharded prover hands
+// over once a layer is small enough to be replicated, zkstark_amd/sharded.py).  Layer rho0 of a
+// (log_n, log_b) proof is layer 0 of a domain with n' = n >> rho0 and shift w^(2^rho0), so the tail
+// is the ordinary fused fold + commit loop of prove_resident on that domain, driven by the caller's
+// channel.
+int zk_tail_create(int device, uint32_t log_n_tail, uint32_t log_b, uint32_t shift, zk_ctx** out) {
+    if (!out) return fail(ZK_ERR_INVALID, "zk_tail_create: out is null");
+    *out = nullptr;
+    if (log_n_tail < 1 || log_b < 1 || log_b > 5 || log_n_tail + log_b > 30)
+        return fail(ZK_ERR_INVALID, "zk_tail_create: bad sizes (%u, %u)", log_n_tail, log_b);
+    return ctx_make(device, log_n_tail, log_b, shift, true, out);
+}
+
+int zk_tail_run(zk_ctx* c, const uint32_t* d_layer0, void* src_stream, zk_channel* chan, int hash_kind,
+                uint32_t* betas_out, uint8_t* roots_out, uint32_t* free_term_out) {
+    if (!c || !c->tail || !d_layer0 || !chan || !betas_out || !roots_out || !free_term_out)
+        return fail(ZK_ERR_INVALID, "zk_tail_run: bad argument");
+    if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_tail_run: unknown hash %d", hash_kind);
+    HIPCHK(hipSetDevice(c->device));
+    c->hash = hash_kind;
+    HIPCHK(hipStreamSynchronize((hipStream_t)src_stream));           // the producer of d_layer0 ran on another stream
+    HIPCHK(hipMemcpyAsync(c->d_layers + c->layer_off[1], d_layer0, c->N * 4, hipMemcpyDeviceToDevice, c->stream));
+    Channel& ch = chan->ch;
+    uint8_t root[32];
+    int rc;
+    if ((rc = do_merkle(c, 1))) return rc;                             // prover.rs:214 for the handed-over layer
+    if ((rc = read_root(c, 1, root))) return rc;
+    ch.commit_hash(root);                                              // prover.rs:224
+    memcpy(roots_out, root, 32);
+    for (uint32_t r = 0; r < c->R; ++r) {                              // prover.rs:198-225
+        uint32_t beta = betas_out[r] = ch.get_u32();
+        if ((rc = do_fold_commit(c, r, beta))) return rc;
+        if ((rc = read_root(c, 2 + r, root))) return rc;
+        ch.commit_hash(root);
+        memcpy(roots_out + 32 * (r + 1), root, 32);
+    }
+    HIPCHK(hipMemcpyAsync(c->h_small, c->d_layers + c->layer_off[1 + c->R], c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 1; i < c->B; ++i)
+        if (c->h_small[i] != c->h_small[0])
+            return fail(ZK_ERR_CHECK, "last FRI layer is not constant (prover.rs:238)");
+    *free_term_out = c->h_small[0];
+    return ZK_OK;
+}
+
+// Openings of the tail layers for global query index x (prover.rs:280-289): for tail layer i < R,
+// vals_out[2i], vals_out[2i+1] = layer[xi], layer[nx]; the two paths (L - i digests each) follow each
+// other in paths_out.  Total digests: sum 2 (L - i).
+int zk_tail_open(zk_ctx* c, size_t x, uint32_t* vals_out, uint8_t* paths_out) {
+    if (!c || !c->tail || !vals_out || !paths_out) return fail(ZK_ERR_INVALID, "zk_tail_open: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<uint64_t> voff, doff;
+    std::vector<size_t> nodes;
+    for (uint32_t i = 0; i < c->R; ++i) {
+        size_t len = c->N >> i, xi = x % len, nx = (xi + len / 2) % len;
+        for (size_t leaf : {xi, nx}) {
+            voff.push_back(c->layer_off[1 + i] + leaf);
+            nodes.clear();
+            path_nodes(len, leaf, nodes);
+            for (size_t nd : nodes) doff.push_back((uint64_t)c->tree_off[1 + i] + (uint64_t)nd * 8);
+        }
+    }
+    const size_t nv = voff.size(), ndg = doff.size();
+    if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
+    if (nv == 0) return ZK_OK;
+    memcpy(c->h_gather_off, voff.data(), nv * 8);
+    memcpy(c->h_gather_off + nv, doff.data(), ndg * 8);
+    HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, (nv + ndg) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream, prof_of(c)));
+    HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream, prof_of(c)));
+    HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(vals_out, c->h_gather_out, nv * 4);
+    for (size_t i = 0; i < ndg; ++i) digest_words_to_bytes(c->h_gather_out + nv + 8 * i, paths_out + 32 * i);
+    return ZK_OK;
+}
 int zk_channel_new(zk_channel** out) {
     if (!out) return fail(ZK_ERR_INVALID, "null argument");
     *out = new (std::nothrow) zk_channel();

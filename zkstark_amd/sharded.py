@@ -136,7 +136,9 @@ class HipBackend:
     def close(self):
         for h in self._doms:
             self.lib.zk_dom_destroy(h)
-        self._doms = []
+        for h in getattr(self, "_tails", []):
+            self.lib.zk_ctx_destroy(h)
+        self._doms, self._tails = [], []
 
     def empty(self, nwords):
         return self.torch.empty(nwords, dtype=self.torch.int32, device=self.device)
@@ -174,6 +176,29 @@ class HipBackend:
     def sync(self):
         self.torch.cuda.current_stream(self.device).synchronize()
 
+    # FRI tail in one C call (zk_tail_*): the replicated small layers need no collectives, so the
+    # per-round Python and readback cost is dropped for them
+    def tail_create(self, log_n_tail, log_b, shift):
+        h = C.c_void_p()
+        check(self.lib.zk_tail_create(self.index, log_n_tail, log_b, shift, C.byref(h)))
+        self._tails = getattr(self, "_tails", []) + [h]
+        return h
+
+    def tail_run(self, tail, layer, channel, rounds, hash_kind=0):
+        betas = (C.c_uint32 * max(rounds, 1))()
+        roots = C.create_string_buffer(32 * (rounds + 1))
+        free_term = C.c_uint32()
+        check(self.lib.zk_tail_run(tail, layer.data_ptr(), self._stream(), channel._h, hash_kind, betas, roots,
+                                   C.byref(free_term)))
+        return list(betas)[:rounds], [roots.raw[32 * i:32 * i + 32] for i in range(rounds + 1)], free_term.value
+
+    def tail_open(self, tail, x, rounds, log_size):
+        ndig = sum(2 * (log_size - i) for i in range(rounds))
+        vals = (C.c_uint32 * max(2 * rounds, 1))()
+        paths = C.create_string_buffer(max(32 * ndig, 1))
+        check(self.lib.zk_tail_open(tail, x, vals, paths))
+        return list(vals)[:2 * rounds], paths.raw[:32 * ndig]
+
 
 class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
@@ -196,7 +221,13 @@ class ShardedProver:
         self.shift = GEN_W * _pow(h, self.rank) % P
         be = self.be
         self.dom_loc = be.domain(log_n, log_blowup - self.lg, self.shift)
-        self.dom_glob = be.domain(log_n, log_blowup, GEN_W, fold_only=True) if self.n_sharded <= self.R else None
+        # the replicated tail (layers rho >= n_sharded) runs as one C call when the backend offers it:
+        # layer rho0 is layer 0 of the domain with n' = n >> rho0 and shift w^(2^rho0)
+        self.tail_rounds = self.R - self.n_sharded
+        self.tail = None
+        if hasattr(be, "tail_create") and self.tail_rounds >= 1:
+            self.tail = be.tail_create(self.tail_rounds, log_blowup, _pow(GEN_W, 1 << self.n_sharded))
+        self.dom_glob = be.domain(log_n, log_blowup, GEN_W, fold_only=True) if self.n_sharded <= self.R and self.tail is None else None
         # one allocation for layers, one for trees (as the single-GPU context)
         NL = self.N // G
         self.layer_off, self.layer_len, off = [], [], 0
@@ -306,6 +337,11 @@ class ShardedProver:
                     be.interleave(gathered, self._layer(dst_id), lg, m_log - 1 - lg)
                 else:
                     self._layer(dst_id).copy_(piece)
+                if self.tail is not None:
+                    # hand the first replicated layer over: its commitment and every later round in one C call
+                    tb, tr, free_term = be.tail_run(self.tail, self._layer(dst_id), ch, self.tail_rounds)
+                    betas.extend(tb); roots.extend(tr)
+                    break
                 root = self._commit_replicated(dst_id, m_log - 1)
             else:
                 be.fold(self.dom_glob, src, self._layer(dst_id), m_log, rho, beta)
@@ -314,10 +350,11 @@ class ShardedProver:
         # last layer: B equal values (prover.rs:238, :251, :254)
         if self._sharded(R):
             raise ZkError(-4, "last FRI layer still sharded: lower min_chunk_log only with a tiny world")
-        last = be.to_host(self._layer(1 + R))
-        if not (last == last[0]).all():
-            raise ZkError(-7, "last FRI layer is not constant (prover.rs:238)")
-        free_term = int(last[0])
+        if self.tail is None:
+            last = be.to_host(self._layer(1 + R))
+            if not (last == last[0]).all():
+                raise ZkError(-7, "last FRI layer is not constant (prover.rs:238)")
+            free_term = int(last[0])
         ch.commit(free_term)                                                        # prover.rs:254
         x = ch.get_u32() % (N - 2 * B)                                              # prover.rs:263
         self.transcript = {"alpha_raw": alphas, "beta_raw": betas, "roots": roots, "free_term": free_term, "query": x}
@@ -329,7 +366,10 @@ class ShardedProver:
         all-gather merges them, every rank assembles the same bytes."""
         be, G, lg, L, R, B, N = self.be, self.G, self.lg, self.L, self.R, self.B, self.N
         val_items, dig_items = [], []      # (owner or -1, offset)
-        openings = []                      # (lid, leaf, m_log, n_local_digests, top_path or None)
+        openings = []                      # (n_local_digests, top_path) per opening; tail openings come later
+        rho0 = self.n_sharded
+        if self.tail is not None:
+            tvals, tpaths = be.tail_open(self.tail, x, self.tail_rounds, L - rho0)
 
         def add_opening(lid, leaf, m_log, sharded):
             if sharded:
@@ -351,7 +391,8 @@ class ShardedProver:
 
         for lid, leaf in ((0, x), (0, x + B), (0, x + 2 * B), (1, x)):               # prover.rs:266-277
             add_opening(lid, leaf, L, True)
-        for i in range(R):                                                            # prover.rs:280-289
+        n_gathered_layers = rho0 if self.tail is not None else R
+        for i in range(n_gathered_layers):                                            # prover.rs:280-289
             ln = N >> i
             xi = x % ln
             nx = (xi + ln // 2) % ln
@@ -387,9 +428,18 @@ class ShardedProver:
         for k in range(4):                                                            # prover.rs:274-277
             b = struct.pack("<I", int(V[k])) + blobs[k]
             check(lib.zk_channel_commit(h, b, len(b)))
-        for i in range(R):                                                            # prover.rs:288
+        for i in range(n_gathered_layers):                                            # prover.rs:288
             b = struct.pack("<II", int(V[4 + 2 * i]), int(V[5 + 2 * i])) + blobs[4 + 2 * i] + blobs[5 + 2 * i]
             check(lib.zk_channel_commit(h, b, len(b)))
+        if self.tail is not None:                                                     # tail layers, from zk_tail_open
+            tp = 0
+            for j in range(self.tail_rounds):
+                pl = L - rho0 - j
+                b = (struct.pack("<II", tvals[2 * j], tvals[2 * j + 1])
+                     + struct.pack("<Q", pl) + tpaths[32 * tp:32 * (tp + pl)]
+                     + struct.pack("<Q", pl) + tpaths[32 * (tp + pl):32 * (tp + 2 * pl)])
+                tp += 2 * pl
+                check(lib.zk_channel_commit(h, b, len(b)))
 
     def close(self):
         self.be.close()
