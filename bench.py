@@ -64,7 +64,15 @@ def cpu_baseline(sample_log_n, log_b):
     t0 = time.perf_counter()
     oracle.prove(sample_log_n - 3, log_b, want_vectors=False)
     dt_one = time.perf_counter() - t0
+    # BASELINE.md plan item 1: the reference's own algorithm (naive Lagrange, per-point solve, schoolbook
+    # division; single thread like the reference) at the only size the reference supports, configs[0]
+    t0 = time.perf_counter()
+    rn = oracle.prove(10, 3, mode=oracle.MODE_NAIVE, want_vectors=False)
+    dt_naive = time.perf_counter() - t0
+    assert rn.rc == 0
     return {
+        "reference_algorithm": {"workload": "configs[0]: trace 1023, domain 8192, literal polynomial.rs arithmetic (O(n^3)), 1 thread",
+                                "seconds": dt_naive, "value": 8192 / dt_naive, "unit": "field-elements/s"},
         "value": N / dt_all, "unit": "field-elements/s", "cores": cores, "kind": "port",
         "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads, {dt_all:.2f} s",
         "single_thread_value": (N // 8) / dt_one,
@@ -152,6 +160,18 @@ def main():
                 dt2 = (time.perf_counter() - t0) / 20
             result["lde_commit_2e20"] = {"workload": "configs[1]: domain 2^20 LDE + Merkle commit", "us": dt2 * 1e6,
                                          "value": (1 << 20) / dt2, "unit": "field-elements/s"}
+        if args.hash == "sha256" and not args.no_secondary:
+            # configs[0] on the GPU path: the reference's own size (trace 1023, domain 8192)
+            with zk.Context(10, 3, device=local_rank) as c0:
+                c0.trace_upload(zk.trace_fibsq(1023))
+                for _ in range(3):
+                    c0.prove()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    c0.prove()
+                dt0 = (time.perf_counter() - t0) / 20
+            result["reference_size_2e13"] = {"workload": "configs[0]: full prover, trace 1023, domain 8192", "us": dt0 * 1e6,
+                                             "value": 8192 / dt0, "unit": "field-elements/s"}
         if args.in_flight > 1 and not args.no_secondary:
             # secondary figure: several independent proofs in flight on one GPU (one context, stream and
             # host thread each), so one proof's latency-bound tree tops overlap another's hashing
@@ -230,8 +250,9 @@ def main():
         }
         if "pipelined" in result:
             out["pipelined"] = result["pipelined"]
-        if "lde_commit_2e20" in result:
-            out["lde_commit_2e20"] = result["lde_commit_2e20"]
+        for k in ("lde_commit_2e20", "reference_size_2e13"):
+            if k in result:
+                out[k] = result[k]
         if world == 1 and not args.no_cpu_baseline and args.hash == "sha256":
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
         print(json.dumps(out), flush=True)
