@@ -68,6 +68,7 @@ uint32_t zk_field_pow(uint32_t a, uint32_t e);       /* field.rs:26-38 */
 uint32_t zk_field_from_u32(uint32_t v);              /* field.rs:20-24 */
 uint32_t zk_field_generator(void);                   /* field.rs:52-86 -> 5 */
 uint32_t zk_field_root_of_unity(uint32_t log_order); /* prover.rs:48-49 */
+uint32_t zk_field_order(uint32_t a);                 /* field.rs:45-49 (via P-1 = 3*2^30, not brute force) */
 
 /* ---- context ------------------------------------------------------------- */
 /* Allocates HBM for a proof with trace group size n = 2^log_n and blow-up
@@ -237,6 +238,12 @@ int zk_dev_compose(const zk_dom *dom, const uint32_t *d_f, uint32_t *d_cp, uint3
 /* polynomial.rs:385 + prover.rs:204-211: 2^log_m values of FRI layer `round` -> 2^(log_m-1). */
 int zk_dev_fri_fold(const zk_dom *dom, const uint32_t *d_in, uint32_t *d_out, uint32_t log_m, uint32_t round,
                     uint32_t beta_raw, void *stream);
+/* Batch trace generation: prover.rs:32-39 is serial per trace, so one
+ * lane generates one trace; out[t*count + i] = a_i of trace t seeded by (a0[t], a1[t]). */
+int zk_dev_trace_fibsq_batch(const uint32_t *d_a0, const uint32_t *d_a1, uint32_t batch, uint32_t count,
+                             uint32_t *d_out, void *stream);
+int zk_trace_fibsq_batch_host(int device, const uint32_t *a0, const uint32_t *a1, uint32_t batch,
+                              uint32_t count, uint32_t *out);
 /* out[u * parts + q] = in[q * cnt + u]: cyclic <-> block layout around the all-to-all. */
 int zk_dev_interleave(const uint32_t *d_in, uint32_t *d_out, uint32_t log_parts, uint32_t log_cnt, void *stream);
 /* d_out[i*words ..] = d_src[d_offsets[i] .. + words]. */

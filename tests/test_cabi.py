@@ -58,6 +58,10 @@ def test_field_matches_oracle(zk, orc):
         assert f.neg(a) == (-a) % P
     for a in (1, 2, 5, P - 1, 123456789):
         assert f.mul(a, f.inv(a)) == 1
+    assert f.order(f.root_of_unity(10)) == 1024 and f.order(f.root_of_unity(13)) == 8192   # prover.rs:52-53
+    assert f.order(5) == P - 1 and f.order(1) == 1 and f.order(P - 1) == 2
+    for a in (2, 3, 7, 12345):
+        assert f.pow(a, f.order(a)) == 1
     assert f.from_u32(3235878091) == 3235878091 - P        # field.rs:20-24: reduce raw u32 >= P
     assert f.add(P - 1, P - 1) == P - 2                    # P > 2^31: a + b overflows u32
 

@@ -288,3 +288,12 @@ def test_prover_multi_query(zk, orc, q):
         proof = ctx.prove(zk.trace_fibsq(1023))
     assert proof.data == want.proof and proof.state == want.state
     proof.verify(strict=True)
+
+
+def test_trace_fibsq_batch_on_device(zk, orc):
+    """batch trace generation, one lane per trace, equals the host recurrence (prover.rs:32-39)."""
+    a1s = [3141592, 7, 99, P - 1, 0, 123456789] * 20
+    got = zk.trace_fibsq_batch([1] * len(a1s), a1s, 1023)
+    assert got[0][1022] == 2338775057                        # prover.rs:42
+    for t in (0, 1, 3, 5, 119):
+        assert np.array_equal(got[t], orc.trace_fibsq(1023, 1, a1s[t]))

@@ -49,6 +49,9 @@ SYMBOLS = {
     "zk_field_from_u32": (_u32, [_u32]),
     "zk_field_generator": (_u32, []),
     "zk_field_root_of_unity": (_u32, [_u32]),
+    "zk_field_order": (_u32, [_u32]),
+    "zk_dev_trace_fibsq_batch": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "zk_trace_fibsq_batch_host": (_int, [_int, _vp, _vp, _u32, _u32, _vp]),
     "zk_ctx_create": (_int, [_int, _u32, _u32, C.POINTER(_vp)]),
     "zk_ctx_destroy": (_int, [_vp]),
     "zk_ctx_setup_ms": (_dbl, [_vp]),

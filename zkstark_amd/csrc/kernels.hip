@@ -21,6 +21,8 @@ __device__ __forceinline__ uint32_t pow_lookup(const PowTable& t, uint32_t e) {
     return mont_mul(t.hi[e >> t.lo_bits], t.lo[e & ((1u << t.lo_bits) - 1u)]);
 }
 
+constexpr uint32_t R2_MONT = R2;   // 2^64 mod P (fieldhash.hpp): canonical -> Montgomery
+
 // Montgomery-domain inverse by Fermat: a^(P-2), P-2 = 0xBFFFFFFF.
 __device__ uint32_t mont_inv(uint32_t a) {
     uint32_t r = R1, b = a;
@@ -662,6 +664,33 @@ hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s,
 // composition + commit of cp layer 0 (a.cp receives it): one pass
 hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {
     return merkle_build_t(ComposeSrc{a}, 8.0 * (double)((size_t)1 << a.logN), a.logN, nodes, s, prof, mailbox, seq, hash);
+}
+
+// ===========================================================================
+// Trace generation for batches
+// ===========================================================================
+// prover.rs:32-39 is a serial recurrence, so one trace cannot be parallelised; many independent
+// traces can.  One lane per trace: out[t*count + i] = a_i of trace t (a0[t], a1[t] seeds).
+__global__ __launch_bounds__(64) void trace_fibsq_batch_kernel(const uint32_t* a0, const uint32_t* a1, uint32_t batch,
+                                                               uint32_t count, uint32_t* out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch) return;
+    uint32_t* row = out + (size_t)t * count;
+    // Montgomery domain: squares of Montgomery values stay Montgomery
+    uint32_t x = mont_mul(a0[t], R2_MONT), y = mont_mul(a1[t], R2_MONT);
+    if (count > 0) row[0] = mont_mul(x, 1u);
+    if (count > 1) row[1] = mont_mul(y, 1u);
+    for (uint32_t i = 2; i < count; ++i) {
+        uint32_t z = add(mont_mul(x, x), mont_mul(y, y));
+        row[i] = mont_mul(z, 1u);
+        x = y; y = z;
+    }
+}
+
+hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s) {
+    if (!batch) return hipSuccess;
+    hipLaunchKernelGGL(trace_fibsq_batch_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, a0, a1, batch, count, out);
+    return hipGetLastError();
 }
 
 // ===========================================================================

@@ -144,6 +144,9 @@ hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s,
 hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                                  uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
 
+// batch traces of prover.rs:32-39, one lane per trace: out[t*count + i]
+hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s);
+
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
                          uint32_t* out, hipStream_t s, Profiler* prof = nullptr);

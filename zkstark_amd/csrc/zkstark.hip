@@ -550,6 +550,15 @@ uint32_t zk_field_inv(uint32_t a) { return invmod(a % P); }
 uint32_t zk_field_pow(uint32_t a, uint32_t e) { return powmod(a, e); }
 uint32_t zk_field_from_u32(uint32_t v) { return v % P; }
 uint32_t zk_field_generator(void) { return GEN_W; }
+// field.rs:45-49 order(): the reference brute-forces it; P - 1 = 3 * 2^30 gives it in 32 squarings
+uint32_t zk_field_order(uint32_t a) {
+    a %= P;
+    if (a == 0) return 0;
+    uint32_t ord = P - 1;
+    if (powmod(a, ord / 3) == 1) ord /= 3;
+    while (ord % 2 == 0 && powmod(a, ord / 2) == 1) ord /= 2;
+    return ord;
+}
 uint32_t zk_field_root_of_unity(uint32_t log_order) { return log_order > 30 ? 0 : root_of_unity(log_order); }
 
 static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool tail, zk_ctx** out);
@@ -1010,6 +1019,26 @@ int zk_dev_fri_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint
                     uint32_t beta_raw, void* stream) {
     if (!d || !d_in || !d_out) return fail(ZK_ERR_INVALID, "zk_dev_fri_fold: null argument");
     return dom_fold(d, d_in, d_out, log_m, round, beta_raw, (hipStream_t)stream, dev_prof());
+}
+int zk_dev_trace_fibsq_batch(const uint32_t* d_a0, const uint32_t* d_a1, uint32_t batch, uint32_t count, uint32_t* d_out, void* stream) {
+    if ((batch && (!d_a0 || !d_a1 || !d_out))) return fail(ZK_ERR_INVALID, "zk_dev_trace_fibsq_batch: null argument");
+    HIPCHK(launch_trace_fibsq_batch(d_a0, d_a1, batch, count, d_out, (hipStream_t)stream));
+    return ZK_OK;
+}
+int zk_trace_fibsq_batch_host(int device, const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out) {
+    if (batch && (!a0 || !a1 || !out)) return fail(ZK_ERR_INVALID, "zk_trace_fibsq_batch_host: null argument");
+    if (!batch || !count) return ZK_OK;
+    HIPCHK(hipSetDevice(device));
+    uint32_t *d0 = nullptr, *d1 = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&d0, batch * 4)); HIPCHK(hipMalloc(&d1, batch * 4));
+    hipError_t e = hipMalloc(&dout, (size_t)batch * count * 4);
+    int rc = ZK_OK;
+    if (e != hipSuccess) rc = fail(ZK_ERR_NOMEM, "hipMalloc failed");
+    if (!rc && (hipMemcpy(d0, a0, batch * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d1, a1, batch * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = fail(ZK_ERR_HIP, "H2D failed");
+    if (!rc && launch_trace_fibsq_batch(d0, d1, batch, count, dout, nullptr) != hipSuccess) rc = fail(ZK_ERR_HIP, "launch failed");
+    if (!rc && hipMemcpy(out, dout, (size_t)batch * count * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ZK_ERR_HIP, "D2H failed");
+    (void)hipFree(d0); (void)hipFree(d1); if (dout) (void)hipFree(dout);
+    return rc;
 }
 int zk_dev_interleave(const uint32_t* d_in, uint32_t* d_out, uint32_t log_parts, uint32_t log_cnt, void* stream) {
     if (!d_in || !d_out || log_parts + log_cnt > 31) return fail(ZK_ERR_INVALID, "zk_dev_interleave: bad argument");

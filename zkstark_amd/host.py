@@ -45,12 +45,22 @@ class field:
     def generator(): return _lib.load().zk_field_generator()
     @staticmethod
     def root_of_unity(log_order): return _lib.load().zk_field_root_of_unity(log_order)
+    @staticmethod
+    def order(a): return _lib.load().zk_field_order(a)     # field.rs:45-49
 
 
 def trace_fibsq(count, a0=1, a1=3141592):
     """prover.rs:32-39."""
     out = np.zeros(count, dtype=np.uint32)
     check(_lib.load().zk_trace_fibsq(a0, a1, count, _ptr(out)))
+    return out
+
+
+def trace_fibsq_batch(a0s, a1s, count, device=0):
+    """Many independent traces on the GPU, one lane each: returns [batch, count]."""
+    a0s, a1s = _u32arr(a0s), _u32arr(a1s)
+    out = np.zeros((len(a0s), count), dtype=np.uint32)
+    check(_lib.load().zk_trace_fibsq_batch_host(device, _ptr(a0s), _ptr(a1s), len(a0s), count, _ptr(out)))
     return out
 
 
