@@ -78,7 +78,7 @@ def test_lde_reference_checkpoints(zk):
     assert list(f[-3:]) == [800520420, 1199720174, 1076821037]
 
 
-@pytest.mark.parametrize("log_n,log_b", [(2, 1), (4, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1)])
+@pytest.mark.parametrize("log_n,log_b", [(2, 1), (4, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1), (9, 5), (16, 5), (20, 2)])
 def test_lde_matches_oracle(zk, orc, log_n, log_b):
     rng = np.random.default_rng(300 + log_n * 8 + log_b)
     trace = rand_field(rng, (1 << log_n) - 1)   # arbitrary trace values, not only Fibonacci-square
@@ -139,7 +139,7 @@ def test_generate_proof_staged_equals_one_call(zk):
     p1.verify()
 
 
-@pytest.mark.parametrize("log_n,log_b,a1", [(2, 1, 3141592), (4, 3, 7), (6, 2, 3141592), (12, 3, 99), (15, 3, 3141592), (17, 3, 5)])
+@pytest.mark.parametrize("log_n,log_b,a1", [(2, 1, 3141592), (4, 3, 7), (6, 2, 3141592), (12, 3, 99), (15, 3, 3141592), (17, 3, 5), (11, 5, 3), (18, 1, 3141592), (7, 4, 11)])
 def test_prover_other_sizes(zk, orc, log_n, log_b, a1):
     want = orc.prove(log_n, log_b, 1, a1, want_vectors=False)
     assert want.rc == 0
@@ -297,3 +297,27 @@ def test_trace_fibsq_batch_on_device(zk, orc):
     assert got[0][1022] == 2338775057                        # prover.rs:42
     for t in (0, 1, 3, 5, 119):
         assert np.array_equal(got[t], orc.trace_fibsq(1023, 1, a1s[t]))
+
+
+def test_repeated_proofs_are_identical(zk):
+    """Determinism under load (a latent LDS or hand-off race would show as a differing proof):
+    many proofs from one resident trace, two contexts proving concurrently from two host threads."""
+    import threading
+    a = zk.trace_fibsq((1 << 15) - 1)
+    with zk.Context(15, 3) as c1, zk.Context(15, 3) as c2:
+        c1.trace_upload(a); c2.trace_upload(a)
+        ref = c1.prove()
+        out = {}
+
+        def work(name, c):
+            out[name] = [c.prove().data for _ in range(40)]
+        th = [threading.Thread(target=work, args=(n, c)) for n, c in (("a", c1), ("b", c2))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    assert all(d == ref.data for d in out["a"] + out["b"])
+    b = zk.trace_fibsq((1 << 21) - 1)
+    with zk.Context(21, 3) as c3:
+        c3.trace_upload(b)
+        first = c3.prove()
+        assert all(c3.prove().data == first.data for _ in range(6))
+    first.verify(strict=True)
