@@ -40,6 +40,8 @@ __device__ uint32_t mont_inv(uint32_t a) {
 // NTT passes
 // ===========================================================================
 //
+// Generic pass for any radix and size (the full-size tiles with R = 64/128/256 take the
+// register-radix kernel of ntt_fast.hip instead; this one serves small transforms and odd radices).
 // The array is viewed as [A][R][S] with S fastest.  A workgroup owns a tile of C
 // columns (a, s) and all R rows t of those columns, stages it in LDS with row
 // pitch C+1, runs the log2(R) radix-2 stages there and writes the tile back in
