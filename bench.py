@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 
 # 256 CUs x 64 lanes x 2.4 GHz = 39.3 T lane-ops/s nominal; 35 T measured at the clock the chip holds.
 VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
+PROFILE_VALU = os.path.join(ROOT, "profiles", "valu_utilization.json")   # PMC-derived VALU issue utilisation
 
 
 def parse():
@@ -211,6 +212,14 @@ def main():
         if os.path.exists(PROFILE_TRAFFIC):
             with open(PROFILE_TRAFFIC) as f:
                 traffic = json.load(f).get("merkle_leaf_bytes_per_launch")
+        hw_valu = None
+        if os.path.exists(PROFILE_VALU):
+            with open(PROFILE_VALU) as f:
+                ks = [k for k in json.load(f)["kernels"] if "merkle_subtree_kernel" in k["kernel"] and ", true," in k["kernel"]]
+            if ks:   # the largest leaf launch: issue-slot utilisation and the clock the chip held (hardware counters)
+                big = max(ks, key=lambda k: k["duration_us"])
+                hw_valu = {"utilization": big["valu_utilization"], "clock_ghz": big["clock_ghz"], "kernel": big["kernel"],
+                           "source": "rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE (profiles/valu_utilization.json)"}
         # SHA-256 work of the dominant kernel in 32-bit lane-ops (1 leaf + inner hashes)
         roofline = {
             "kernel": "merkle_subtree_kernel<leaf>", "bound": "hbm",
@@ -223,7 +232,8 @@ def main():
                      "unit": "T lane-ops/s (32-bit)",
                      "frac": (dom["ops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS) if dom["ms"] > 0 else 0.0,
                      "ops_per_leaf_hash": 1259 if args.hash == "sha256" else 10200,
-                     "ops_per_inner_hash": 2293 if args.hash == "sha256" else 10300},
+                     "ops_per_inner_hash": 2293 if args.hash == "sha256" else 10300,
+                     "hw_counters": hw_valu if args.hash == "sha256" else None},
         }
         stages = []
         for name, st in result["per_kernel"].items():
