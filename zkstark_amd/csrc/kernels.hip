@@ -11,6 +11,8 @@
 // No MFMA anywhere: butterflies and SHA rounds are not a dense contraction.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 #include "field.hpp"
 #include "fieldhash.hpp"
 #include "sha256.hpp"
@@ -602,7 +604,15 @@ static hipError_t ensure_fieldhash_consts() {
 // Throughput phase: subtree launches (k <= 4 levels each) while the level has more than 2^18 nodes,
 // i.e. while there are more than ~4 waves per SIMD to keep busy.  Latency phase: workgroup launches
 // of up to 10 levels each.
-constexpr uint32_t kMerkleLatencyLog = 18;
+constexpr uint32_t kMerkleLatencyLogDefault = 17;   // measured flat optimum 16..18 (profiles/README.md)
+static uint32_t merkle_latency_log() {            // ZK_MERKLE_LATENCY_LOG overrides (tuning only)
+    static const uint32_t v = [] {
+        const char* e = getenv("ZK_MERKLE_LATENCY_LOG");
+        uint32_t x = e ? (uint32_t)atoi(e) : kMerkleLatencyLogDefault;
+        return (x < 12 || x > 24) ? kMerkleLatencyLogDefault : x;
+    }();
+    return v;
+}
 
 template <class SRC>
 static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
@@ -616,6 +626,7 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
     const PlainSrc none{nullptr};
     // the first launch reads its leaves through SRC: replace the plain 4 B/leaf read by the source's bytes
     auto first_bytes = [&](double b) { return leaf ? b - 4.0 * (double)((size_t)1 << log_m) + src_bytes : b; };
+    const uint32_t kMerkleLatencyLog = merkle_latency_log();
     while (depth > kMerkleLatencyLog) {
         uint32_t k = depth - kMerkleLatencyLog;
         if (k > kMerkleMaxK) k = kMerkleMaxK;
