@@ -1,0 +1,33 @@
+"""The product's host-only code (transcript.hpp: channel, wire format, verifier; fieldhash.hpp on the
+host) compiled with g++ -fsanitize=address,undefined and run on valid, truncated, bit-flipped and random
+proofs.  CPU only (GPU sanitizers are not available on the pool)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("san") / "host_sanitizer_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "host_sanitizer_check.cpp"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("log_n,log_b,hash_kind", [(6, 2, 0), (10, 3, 0), (5, 1, 1)])
+def test_verifier_memory_safety(orc, checker, tmp_path, log_n, log_b, hash_kind):
+    try:
+        orc.set_hash(hash_kind)
+        r = orc.prove(log_n, log_b, want_vectors=False)
+    finally:
+        orc.set_hash(0)
+    assert r.rc == 0
+    p = tmp_path / "proof.bin"
+    p.write_bytes(r.proof)
+    out = subprocess.run([checker, str(p), str(log_n), str(log_b), str(r.public_last), str(hash_kind)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok: valid accepted" in out.stdout
