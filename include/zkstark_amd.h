@@ -252,6 +252,10 @@ int zk_dev_gather(const uint32_t *d_src, const uint64_t *d_offsets, uint32_t cou
 /* d_vals: m u32 on the device; d_nodes: (2m-1)*8 u32 state words, heap order. */
 int zk_dev_merkle_build(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_nodes, void *stream);
 int zk_dev_merkle_build_ex(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_nodes, void *stream, int hash_kind);
+/* Same tree, with the leaves still in all-to-all order: 2^log_parts pieces of 2^log_cnt words, leaf
+ * u*parts + q = d_recv[q*cnt + u] (zk_dev_interleave fused into the leaf hashing). */
+int zk_dev_merkle_build_interleaved(const uint32_t *d_recv, uint32_t log_parts, uint32_t log_cnt,
+                                    uint32_t *d_nodes, void *stream, int hash_kind);
 /* Byte view of nodes stored as state words: out[32] for node `index`. */
 int zk_dev_merkle_node(const uint32_t *d_nodes, size_t index, uint8_t out[32], void *stream);
 

@@ -389,6 +389,14 @@ struct ComposeSrc {    // cp layer 0 from f_eval: prover.rs:101-173 + :176
     __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = compose_at(a, pos); a.cp[pos] = v; return v; }
 };
 
+struct InterleaveSrc { // leaves arrive as 2^log_parts cyclic pieces of 2^log_cnt words (multi-GPU all-to-all output):
+    const uint32_t* recv;  // leaf u*parts + q = recv[q*cnt + u]; hashed straight from the receive buffer
+    uint32_t log_parts, log_cnt;
+    __device__ __forceinline__ uint32_t load(size_t pos) const {
+        return recv[((pos & (((size_t)1 << log_parts) - 1)) << log_cnt) | (pos >> log_parts)];
+    }
+};
+
 constexpr int kMerkleThreads = 256;
 constexpr uint32_t kMerkleMaxK = 4;
 
@@ -668,6 +676,12 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
                                uint32_t* mailbox, uint32_t seq, int hash) {
     return merkle_build_t(PlainSrc{vals}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, mailbox, seq, hash);
+}
+// commitment of a block whose leaves are still in all-to-all order (no interleave pass, no block buffer)
+hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, hipStream_t s,
+                                           Profiler* prof, int hash) {
+    uint32_t log_m = log_parts + log_cnt;
+    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, nullptr, 0, hash);
 }
 // fold + commit of the folded layer (a.out receives it): one pass
 hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {

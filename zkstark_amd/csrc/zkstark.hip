@@ -1057,6 +1057,12 @@ int zk_dev_merkle_build_ex(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_n
     HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream, dev_prof(), nullptr, 0, hash_kind));
     return ZK_OK;
 }
+int zk_dev_merkle_build_interleaved(const uint32_t* d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* d_nodes, void* stream, int hash_kind) {
+    if (!d_recv || !d_nodes || log_parts + log_cnt > 30 || (hash_kind != 0 && hash_kind != 1))
+        return fail(ZK_ERR_INVALID, "zk_dev_merkle_build_interleaved: bad argument");
+    HIPCHK(launch_merkle_build_interleaved(d_recv, log_parts, log_cnt, d_nodes, (hipStream_t)stream, dev_prof(), hash_kind));
+    return ZK_OK;
+}
 int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
     return zk_dev_merkle_build_ex(d_vals, log_m, d_nodes, stream, ZK_HASH_SHA256);
 }

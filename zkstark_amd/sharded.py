@@ -162,6 +162,10 @@ class HipBackend:
     def merkle(self, vals, log_m, nodes):
         check(self.lib.zk_dev_merkle_build(vals.data_ptr(), log_m, nodes.data_ptr(), self._stream()))
 
+    def merkle_interleaved(self, recv, log_parts, log_cnt, nodes):
+        """Tree over leaves still in all-to-all order (interleave fused into the leaf hashing)."""
+        check(self.lib.zk_dev_merkle_build_interleaved(recv.data_ptr(), log_parts, log_cnt, nodes.data_ptr(), self._stream(), 0))
+
     def gather(self, src, offsets, words):
         """Returns a host uint32 array [len(offsets), words]."""
         torch = self.torch
@@ -284,13 +288,16 @@ class ShardedProver:
         loc = self._layer(lid)
         cnt = loc.numel()
         recv, block = self.recv[:cnt], self.block[:cnt]
+        nodes = self._tree(lid)
         if G > 1 or self.comm.force:
             self.comm.all_to_all(loc, recv)                       # chunk q: rank q's j in my block
-            be.interleave(recv, block, lg, m_log - 2 * lg)        # block[u*G + q] = recv[q][u]
+            if hasattr(be, "merkle_interleaved"):                 # leaf u*G + q = recv[q][u], hashed in place
+                be.merkle_interleaved(recv, lg, m_log - 2 * lg, nodes)
+            else:
+                be.interleave(recv, block, lg, m_log - 2 * lg)    # block[u*G + q] = recv[q][u]
+                be.merkle(block, m_log - lg, nodes)
         else:
-            block = loc
-        nodes = self._tree(lid)
-        be.merkle(block, m_log - lg, nodes)
+            be.merkle(loc, m_log - lg, nodes)
         if G > 1 or self.comm.force:
             self.comm.all_gather(nodes[:8], self.subroot_all)
             words = be.to_host(self.subroot_all).reshape(G, 8)
