@@ -342,3 +342,24 @@ def test_c_abi_from_plain_c(tmp_path):
     head = " ".join(canon["proof_hex"][2 * i:2 * i + 2] for i in range(8))
     assert "proof head: " + head in out.stdout
     assert "final state: " + " ".join(canon["final_state"][2 * i:2 * i + 2] for i in range(8)) in out.stdout
+
+
+@pytest.mark.parametrize("log_m", [4, 10, 14])
+def test_ntt_edge_values(zk, orc, log_m):
+    """Field edge cases through the butterflies: 0, 1, P-1 (a + b overflows u32 since P > 2^31), deltas, constants."""
+    m = 1 << log_m
+    root = orc.gen_of_order_log(log_m)
+    vecs = [np.zeros(m, dtype=np.uint32), np.full(m, P - 1, dtype=np.uint32), np.ones(m, dtype=np.uint32)]
+    d = np.zeros(m, dtype=np.uint32); d[1] = P - 1
+    alt = np.where(np.arange(m) % 2 == 0, P - 1, 1).astype(np.uint32)
+    half = np.full(m, (P - 1) // 2 + 1, dtype=np.uint32)      # 2 * half = P + 1: wraps exactly once
+    for x in vecs + [d, alt, half]:
+        assert np.array_equal(zk.ntt(x), orc.ntt(x, root))
+        assert np.array_equal(zk.ntt(x, inverse=True), orc.intt(x, root))
+
+
+def test_lde_edge_traces(zk, orc):
+    """Traces of all zeros / all P-1 (the virtual point and coset scaling with extreme operands)."""
+    for fill in (0, P - 1, 1):
+        t = np.full(255, fill, dtype=np.uint32)
+        assert np.array_equal(zk.lde(t, 8, 3), orc.lde(t, 8, 3))
