@@ -363,3 +363,24 @@ def test_lde_edge_traces(zk, orc):
     for fill in (0, P - 1, 1):
         t = np.full(255, fill, dtype=np.uint32)
         assert np.array_equal(zk.lde(t, 8, 3), orc.lde(t, 8, 3))
+
+
+def test_compose_and_fold_edge_challenges(zk, orc):
+    """Raw challenges 0, P (== 0), P+1, 2^32-1 (field.rs:20-24 reduction) and extreme layer values."""
+    log_n, log_b = 7, 3
+    N = 1 << (log_n + log_b)
+    rng = np.random.default_rng(11)
+    for f in (np.zeros(N, dtype=np.uint32), np.full(N, P - 1, dtype=np.uint32), rand_field(rng, N)):
+        for alphas in ([0, 0, 0], [P, P + 1, 2**32 - 1], [1, P - 1, 5]):
+            with zk.Context(log_n, log_b) as ctx:
+                trace = rand_field(rng, (1 << log_n) - 1); trace[0] = 1
+                ctx.trace_upload(trace)
+                ctx.layer_write(0, f)
+                ctx.compose(alphas)
+                cp = ctx.layer_read(1)
+                assert np.array_equal(cp, orc.compose(f, log_n, log_b, alphas, int(trace[-1])))
+                for r, beta in enumerate((0, P, 2**32 - 1, 1)):
+                    ctx.fri_fold(r, beta)
+                    nxt = ctx.layer_read(2 + r)
+                    assert np.array_equal(nxt, orc.fri_fold_eval(cp if r == 0 else prev, log_n, log_b, r, beta))
+                    prev = nxt
