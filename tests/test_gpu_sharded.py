@@ -140,3 +140,52 @@ def test_sharded_collectives_over_rccl_single_rank(orc):
     p.join(timeout=120)
     assert p.exitcode == 0
     assert data == want.proof and state == want.state
+
+
+def _config4_worker(rank, world, port, log_n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zkstark_amd as zk
+        from zkstark_amd import sharded
+        torch.cuda.set_device(0)
+        be = sharded.HipBackend(0)
+        sp = sharded.ShardedProver(log_n, 3, sharded.Comm(staged=True), be)
+        sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        root = sp.lde_commit()
+        # the cyclic shard itself: element j of rank r is f_eval[r + world * j]
+        shard_head = be.to_host(sp._layer(0)[:4]).tolist()
+        q.put((rank, root, shard_head))
+        sp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_sharded_lde_and_transpose_domain_2e26(zk):
+    """configs[3]: domain 2^26 evaluated by 2 ranks (each its cosets, no communication), all-to-all
+    transpose to natural order, subtree commitment; the root and the shards equal the single-GPU result."""
+    import torch.multiprocessing as mp
+    log_n, world = 23, 2
+    a = zk.trace_fibsq((1 << log_n) - 1)
+    with zk.Context(log_n, 3) as ctx:
+        ctx.trace_upload(a)
+        ctx.lde()
+        want_root = ctx.merkle_commit(0)
+        head = ctx.layer_read(0, 0, 4 * world)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    procs = [mctx.Process(target=_config4_worker, args=(r, world, port, log_n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, root, shard_head in out:
+        assert root == want_root, f"rank {rank}"
+        assert shard_head == [int(head[rank + world * j]) for j in range(4)]

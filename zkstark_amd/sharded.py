@@ -312,6 +312,15 @@ class ShardedProver:
         self.be.merkle(self._layer(lid), m_log, nodes)
         return words_to_bytes(self.be.to_host(nodes[:8]))
 
+    def lde_commit(self):
+        """BASELINE.json configs[3] shape: the sharded LDE (each rank its cosets) followed by the all-to-all
+        transpose and the Merkle commitment; returns the root of f_eval (prover.rs:60-85)."""
+        if not self.have_trace:
+            raise ZkError(-4, "no trace uploaded")
+        self.tops = {}
+        self.be.lde(self.dom_loc, self.trace, self.coef, self._layer(0))
+        return self._commit_sharded(0, self.L)
+
     # ---- the prover ---------------------------------------------------------------------------
     def prove(self):
         if not self.have_trace:
