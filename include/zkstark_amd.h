@@ -256,6 +256,13 @@ int zk_dev_merkle_build_ex(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_n
  * u*parts + q = d_recv[q*cnt + u] (zk_dev_interleave fused into the leaf hashing). */
 int zk_dev_merkle_build_interleaved(const uint32_t *d_recv, uint32_t log_parts, uint32_t log_cnt,
                                     uint32_t *d_nodes, void *stream, int hash_kind);
+/* The same tree in 2^c aligned chunks, so that hashing chunk i overlaps the exchange of chunk i+1: chunk
+ * `chunk` covers leaves [chunk << s, (chunk+1) << s), s = log_parts + log_cnt, arriving in its own
+ * receive buffer in all-to-all order; the throughput-bound levels are built in place in the heap over
+ * 2^log_m leaves.  zk_dev_merkle_finish then runs the latency-bound top of the whole tree once. */
+int zk_dev_merkle_build_chunk(const uint32_t *d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t *d_nodes,
+                              uint32_t log_m, uint32_t chunk, void *stream, int hash_kind);
+int zk_dev_merkle_finish(uint32_t *d_nodes, uint32_t log_m, uint32_t log_chunks, void *stream, int hash_kind);
 /* Byte view of nodes stored as state words: out[32] for node `index`. */
 int zk_dev_merkle_node(const uint32_t *d_nodes, size_t index, uint8_t out[32], void *stream);
 

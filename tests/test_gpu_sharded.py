@@ -25,8 +25,10 @@ def test_sharded_world1_matches_oracle(zk, orc, log_n, log_b):
     sp.close()
 
 
-def _worker(rank, world, port, log_n, log_b, q):
+def _worker(rank, world, port, log_n, log_b, q, lat):
     sys.path.insert(0, ROOT)
+    if lat:
+        os.environ["ZK_MERKLE_LATENCY_LOG"] = str(lat)     # chunk builds hand over at this depth (tuning knob)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -37,7 +39,7 @@ def _worker(rank, world, port, log_n, log_b, q):
         from zkstark_amd import sharded
         torch.cuda.set_device(0)
         be = sharded.HipBackend(0)
-        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(staged=True), be, min_chunk_log=6)
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(staged=True), be, min_chunk_log=6, overlap_min_log=8)
         sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
         proof = sp.prove()
         q.put((rank, proof.data, proof.state, sp.n_sharded))
@@ -46,14 +48,14 @@ def _worker(rank, world, port, log_n, log_b, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,log_b", [(2, 12, 3), (4, 14, 3)])
-def test_sharded_multirank_one_gpu(orc, world, log_n, log_b):
+@pytest.mark.parametrize("world,log_n,log_b,lat", [(2, 12, 3, 0), (4, 14, 3, 0), (2, 16, 3, 12), (4, 16, 2, 13)])
+def test_sharded_multirank_one_gpu(orc, world, log_n, log_b, lat):
     import torch.multiprocessing as mp
     want = orc.prove(log_n, log_b, want_vectors=False)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, q, lat)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=600) for _ in range(world))
@@ -116,7 +118,7 @@ def _nccl_worker(port, log_n, log_b, q):
         import zkstark_amd as zk
         from zkstark_amd import sharded
         be = sharded.HipBackend(0)
-        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(force=True), be, min_chunk_log=6)
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(force=True), be, min_chunk_log=6, overlap_min_log=8)
         sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
         proof = sp.prove()
         dist.barrier()

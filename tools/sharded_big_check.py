@@ -11,13 +11,17 @@ from zkstark_amd import sharded
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 a = zk.trace_fibsq((1 << log_n) - 1)
 be = sharded.HipBackend(0)
-sp = sharded.ShardedProver(log_n, 3, sharded.Comm(force=True), be)
-sp.trace_upload(a)
-p = sp.prove()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-p = sp.prove()
-torch.cuda.synchronize(); print("sharded(1 rank, RCCL) 2^%d: %.1f ms" % (log_n + 3, (time.perf_counter() - t0) * 1e3), flush=True)
-sp.close(); del sp
+for ov in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [None]):
+    sp = sharded.ShardedProver(log_n, 3, sharded.Comm(force=True), be, **({} if ov is None else {"overlap_min_log": ov}))
+    sp.trace_upload(a)
+    p = sp.prove()
+    best = 1e9
+    for _ in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p = sp.prove()
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    print("sharded(1 rank, RCCL, overlap_min_log=%s) 2^%d: %.2f ms" % (ov, log_n + 3, best * 1e3), flush=True)
+    sp.close(); del sp
 torch.cuda.empty_cache()
 with zk.Context(log_n, 3) as ctx:
     ctx.trace_upload(a)

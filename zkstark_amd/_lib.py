@@ -83,6 +83,8 @@ SYMBOLS = {
     "zk_merkle_build_host_ex": (_int, [_int, _vp, _sz, _vp, _int]),
     "zk_dev_merkle_build_ex": (_int, [_vp, _u32, _vp, _vp, _int]),
     "zk_dev_merkle_build_interleaved": (_int, [_vp, _u32, _u32, _vp, _vp, _int]),
+    "zk_dev_merkle_build_chunk": (_int, [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _int]),
+    "zk_dev_merkle_finish": (_int, [_vp, _u32, _u32, _vp, _int]),
     "zk_verify_strict": (_int, [_vp, _sz, _vp, _u32, _u32, _u32]),
     "zk_proof_size": (_sz, [_sz]),
     "zk_proof_data_len": (_sz, [_u32, _u32]),

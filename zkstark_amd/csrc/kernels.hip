@@ -424,12 +424,14 @@ __device__ __forceinline__ Digest lds_digest(const uint4* p) {
 
 template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src, uint32_t* nodes,
-                                                                        uint32_t depth_in, uint32_t k) {
+                                                                        uint32_t depth_in, uint32_t k, size_t off) {
     // per wave: k levels x 2 groups x 64 digests x 2 uint4
     extern __shared__ __attribute__((aligned(16))) uint4 stage[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const size_t gwave = (size_t)blockIdx.x * (kMerkleThreads / 64) + wave;
-    const size_t base = gwave << (6 + k);                        // first input of this wave
+    // first input of this wave; `off` = position of a chunk's first node at this depth (0 for a whole
+    // tree): a chunk is an aligned sub-range of the leaves, built into its place in the heap
+    const size_t base = (gwave << (6 + k)) + off;
     const size_t in_base = ((size_t)1 << depth_in) - 1;
     uint4* my = stage + (size_t)wave * k * 256;
 #pragma unroll 1
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
         Digest d;
         const size_t pos = base + (size_t)i * 64 + lane;         // 64 consecutive inputs: coalesced
         if (LEAF) {
-            d = Hasher<HASH>::leaf(src.load(pos));
+            d = Hasher<HASH>::leaf(src.load(pos - off));      // the source is chunk-local
             store_digest(nodes, in_base + pos, d);
         } else {
             d = load_digest(nodes, in_base + pos);
@@ -480,18 +482,18 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
 // it instead of paying a blit kernel + stream synchronisation per commitment.
 template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t j,
-                                                               uint32_t* mailbox, uint32_t seq) {
+                                                               uint32_t* mailbox, uint32_t seq, size_t off) {
     extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2], then the 16 KiB schedule exchange
     uint32_t* xch = reinterpret_cast<uint32_t*>(lvl + ((size_t)2 << j));
     const uint32_t tid = threadIdx.x;
     const uint32_t cnt = 1u << j;
-    const size_t first = (size_t)blockIdx.x << j;                 // first input of this workgroup
+    const size_t first = ((size_t)blockIdx.x << j) + off;         // first input of this workgroup (off: see merkle_subtree_kernel)
     const size_t in_base = ((size_t)1 << depth_in) - 1;
 #pragma unroll 1
     for (uint32_t i = tid; i < cnt; i += kWgThreads) {
         Digest d;
         if (LEAF) {
-            d = Hasher<HASH>::leaf(src.load(first + i));
+            d = Hasher<HASH>::leaf(src.load(first + i - off));
             store_digest(nodes, in_base + first + i, d);
         } else {
             d = load_digest(nodes, in_base + first + i);
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
         __syncthreads();
     }
-    if (mailbox && depth_in == j && tid == 0) {
+    if (mailbox && depth_in == j && off == 0 && tid == 0) {
         Digest r = lds_digest(&lvl[0]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) __hip_atomic_store(&mailbox[2 + i], r.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -622,54 +624,67 @@ static uint32_t merkle_latency_log() {            // ZK_MERKLE_LATENCY_LOG overr
     return v;
 }
 
+// Builds the levels of a heap over 2^log_m leaves that lie above the aligned leaf range
+// [chunk << log_sub, (chunk + 1) << log_sub), from the leaves (leaf_mode) or from the nodes already
+// present at depth `log_m - log_sub + span` ... up to the chunk's own root at depth log_m - log_sub.
+// A whole tree is chunk 0 with log_sub = log_m.
 template <class SRC>
 static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
-                                 uint32_t* mailbox, uint32_t seq, int hash) {
+                                 uint32_t* mailbox, uint32_t seq, int hash, uint32_t log_sub = 0xffffffffu, size_t chunk = 0,
+                                 bool leaf_mode = true, bool throughput_only = false) {
     if (hash) {
         hipError_t e = ensure_fieldhash_consts();
         if (e != hipSuccess) return e;
     }
+    if (log_sub == 0xffffffffu) log_sub = log_m;
+    const uint32_t stop = log_m - log_sub;            // depth of the chunk root
     uint32_t depth = log_m;
-    bool leaf = true;
+    bool leaf = leaf_mode;
     const PlainSrc none{nullptr};
     // the first launch reads its leaves through SRC: replace the plain 4 B/leaf read by the source's bytes
-    auto first_bytes = [&](double b) { return leaf ? b - 4.0 * (double)((size_t)1 << log_m) + src_bytes : b; };
+    auto first_bytes = [&](double b) { return leaf ? b - 4.0 * (double)((size_t)1 << log_sub) + src_bytes : b; };
     const uint32_t kMerkleLatencyLog = merkle_latency_log();
-    while (depth > kMerkleLatencyLog) {
-        uint32_t k = depth - kMerkleLatencyLog;
+    auto off_at = [&](uint32_t d) { return (size_t)chunk << (d - stop); };   // chunk's first node at depth d
+    // a chunk build (throughput_only) runs the subtree kernels down to the ABSOLUTE depth at which the
+    // whole tree enters its latency phase and stops there; launch_merkle_finish runs that phase once
+    const uint32_t floor_depth = throughput_only ? kMerkleLatencyLog : stop + kMerkleLatencyLog;
+    while (depth > floor_depth) {
+        uint32_t k = depth - floor_depth;
         if (k > kMerkleMaxK) k = kMerkleMaxK;
-        size_t lanes = (size_t)1 << (depth - k);                // >= 2^18: a multiple of the block size
+        size_t lanes = (size_t)1 << (depth - stop - k);         // >= 2^17: a multiple of the block size
         uint32_t blocks = (uint32_t)(lanes / kMerkleThreads);
         size_t sh = (size_t)(kMerkleThreads / 64) * k * 256 * sizeof(uint4);
-        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, first_bytes(merkle_bytes(leaf, depth, k)), s, merkle_ops(leaf, depth, k, hash));
+        ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, first_bytes(merkle_bytes(leaf, depth - stop, k)), s, merkle_ops(leaf, depth - stop, k, hash));
         if (hash) {
-            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k);
-            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k);
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k, off_at(depth));
+            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k, off_at(depth));
         } else {
-            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k);
-            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k);
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k, off_at(depth));
+            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k, off_at(depth));
         }
         leaf = false;
         depth -= k;
     }
+    if (throughput_only) return hipGetLastError();
     do {
         // split the remaining levels evenly over the launches (each <= kWgMaxLog)
-        uint32_t launches = (depth + kWgMaxLog - 1) / kWgMaxLog;
+        uint32_t span = depth - stop;
+        uint32_t launches = (span + kWgMaxLog - 1) / kWgMaxLog;
         if (launches == 0) launches = 1;
-        uint32_t j = (depth + launches - 1) / launches;
-        uint32_t blocks = 1u << (depth - j);
+        uint32_t j = (span + launches - 1) / launches;
+        uint32_t blocks = 1u << (span - j);
         size_t sh = ((size_t)2 << j) * sizeof(uint4) + 2 * 16 * 128 * sizeof(uint32_t);
-        ScopedKernelTimer tm(prof, K_MERKLE_TOP, first_bytes(merkle_bytes(leaf, depth, j)), s, merkle_ops(leaf, depth, j, hash));
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, first_bytes(merkle_bytes(leaf, span, j)), s, merkle_ops(leaf, span, j, hash));
         if (hash) {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq);
-            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq);
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq, off_at(depth));
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq, off_at(depth));
         } else {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq);
-            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq);
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq, off_at(depth));
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq, off_at(depth));
         }
         leaf = false;
         depth -= j;
-    } while (depth > 0);
+    } while (depth > stop);
     return hipGetLastError();
 }
 
@@ -682,6 +697,29 @@ hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_pa
                                            Profiler* prof, int hash) {
     uint32_t log_m = log_parts + log_cnt;
     return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, nullptr, 0, hash);
+}
+// One chunk (1 / 2^log_chunks of the leaves, still in all-to-all order in its own receive buffer) of a
+// tree over 2^log_m leaves: levels up to the chunk root.  launch_merkle_finish joins the chunk roots.
+// Depth at which chunk builds hand over to launch_merkle_finish: the latency switch of the whole tree when
+// the chunks are large enough for the subtree kernels to end there (>= 256 lanes), else the chunk roots.
+static uint32_t chunk_handover_depth(uint32_t log_m, uint32_t log_chunks) {
+    const uint32_t lat = merkle_latency_log();
+    return (log_m > lat && lat >= log_chunks + 8) ? lat : log_chunks;
+}
+hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, uint32_t log_m,
+                                     uint32_t chunk, hipStream_t s, Profiler* prof, int hash) {
+    uint32_t log_sub = log_parts + log_cnt;
+    bool tp_only = chunk_handover_depth(log_m, log_m - log_sub) != log_m - log_sub;
+    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_sub), log_m, nodes, s, prof, nullptr, 0, hash,
+                          log_sub, chunk, true, tp_only);
+}
+// After every chunk of a 2^log_m-leaf tree (2^log_chunks chunks) has been built down to the switch depth:
+// the latency phase of the whole tree, once.
+hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof, int hash) {
+    const uint32_t start = chunk_handover_depth(log_m, log_chunks);   // depth the chunk builds stopped at
+    if (start == 0) return hipSuccess;
+    // the nodes at depth `start` exist: inner mode over a "tree" of 2^start inputs shares the top of the heap
+    return merkle_build_t(PlainSrc{nullptr}, 0.0, start, nodes, s, prof, nullptr, 0, hash, start, 0, false);
 }
 // fold + commit of the folded layer (a.out receives it): one pass
 hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {

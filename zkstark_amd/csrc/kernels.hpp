@@ -140,6 +140,9 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
 
 hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, hipStream_t s,
                                            Profiler* prof = nullptr, int hash = 0);
+hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, uint32_t log_m,
+                                     uint32_t chunk, hipStream_t s, Profiler* prof = nullptr, int hash = 0);
+hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof = nullptr, int hash = 0);
 // Fused producer + commitment: the layer is computed, stored and leaf-hashed in one pass.
 hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                               uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);

@@ -1063,6 +1063,20 @@ int zk_dev_merkle_build_interleaved(const uint32_t* d_recv, uint32_t log_parts, 
     HIPCHK(launch_merkle_build_interleaved(d_recv, log_parts, log_cnt, d_nodes, (hipStream_t)stream, dev_prof(), hash_kind));
     return ZK_OK;
 }
+int zk_dev_merkle_build_chunk(const uint32_t* d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* d_nodes, uint32_t log_m,
+                              uint32_t chunk, void* stream, int hash_kind) {
+    if (!d_recv || !d_nodes || log_m > 30 || log_parts + log_cnt > log_m || (hash_kind != 0 && hash_kind != 1) ||
+        chunk >= (1u << (log_m - log_parts - log_cnt)))
+        return fail(ZK_ERR_INVALID, "zk_dev_merkle_build_chunk: bad argument");
+    HIPCHK(launch_merkle_build_chunk(d_recv, log_parts, log_cnt, d_nodes, log_m, chunk, (hipStream_t)stream, dev_prof(), hash_kind));
+    return ZK_OK;
+}
+int zk_dev_merkle_finish(uint32_t* d_nodes, uint32_t log_m, uint32_t log_chunks, void* stream, int hash_kind) {
+    if (!d_nodes || log_m > 30 || log_chunks > 10 || log_chunks > log_m || (hash_kind != 0 && hash_kind != 1))
+        return fail(ZK_ERR_INVALID, "zk_dev_merkle_finish: bad argument");
+    HIPCHK(launch_merkle_finish(d_nodes, log_m, log_chunks, (hipStream_t)stream, dev_prof(), hash_kind));
+    return ZK_OK;
+}
 int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
     return zk_dev_merkle_build_ex(d_vals, log_m, d_nodes, stream, ZK_HASH_SHA256);
 }

@@ -96,6 +96,14 @@ class Comm:
             self.dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
+    def all_to_all_async(self, send, recv):
+        """As all_to_all, returning an object with .wait() that orders the CURRENT stream after the exchange
+        (RCCL runs it on its own stream, so kernels already queued keep the GPU busy meanwhile)."""
+        if self.staged and send.is_cuda:
+            self.all_to_all(send, recv)
+            return None
+        return self.dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+
     def all_gather(self, t, out):
         """out: [world * len(t)] flat."""
         if self.staged and t.is_cuda:
@@ -162,6 +170,12 @@ class HipBackend:
     def merkle(self, vals, log_m, nodes):
         check(self.lib.zk_dev_merkle_build(vals.data_ptr(), log_m, nodes.data_ptr(), self._stream()))
 
+    def merkle_chunk(self, recv, log_parts, log_cnt, nodes, log_m, chunk):
+        check(self.lib.zk_dev_merkle_build_chunk(recv.data_ptr(), log_parts, log_cnt, nodes.data_ptr(), log_m, chunk, self._stream(), 0))
+
+    def merkle_finish(self, nodes, log_m, log_chunks):
+        check(self.lib.zk_dev_merkle_finish(nodes.data_ptr(), log_m, log_chunks, self._stream(), 0))
+
     def merkle_interleaved(self, recv, log_parts, log_cnt, nodes):
         """Tree over leaves still in all-to-all order (interleave fused into the leaf hashing)."""
         check(self.lib.zk_dev_merkle_build_interleaved(recv.data_ptr(), log_parts, log_cnt, nodes.data_ptr(), self._stream(), 0))
@@ -207,7 +221,7 @@ class HipBackend:
 class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
 
-    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=14):
+    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=14, overlap_min_log=22):
         self.log_n, self.log_b, self.comm, self.be = log_n, log_blowup, comm, backend
         G = comm.world
         self.G, self.rank = G, comm.rank
@@ -249,6 +263,7 @@ class ShardedProver:
         self.recv = be.empty(NL)
         self.block = be.empty(NL)
         self.subroot_all = be.empty(8 * G)
+        self.log_chunks, self.chunk_min_log = 2, max(overlap_min_log, 2 + 6)   # layers with >= 2^22 words per (rank, peer): 4 chunks
         # the first replicated layer arrives as G cyclic pieces before it is interleaved
         self.gbuf = be.empty(max(1, self.N >> self.n_sharded)) if self.n_sharded <= self.R else None
         self.have_trace = False
@@ -289,7 +304,22 @@ class ShardedProver:
         cnt = loc.numel()
         recv, block = self.recv[:cnt], self.block[:cnt]
         nodes = self._tree(lid)
-        if G > 1 or self.comm.force:
+        log_cnt = m_log - 2 * lg                                  # words per (rank, peer) chunk
+        if (G > 1 or self.comm.force) and hasattr(be, "merkle_chunk") and log_cnt >= self.chunk_min_log:
+            # big layer: exchange and hash in K aligned chunks, so that hashing chunk c overlaps the
+            # all-to-all of chunk c+1 (the exchange runs on RCCL's stream)
+            K, lk = 1 << self.log_chunks, self.log_chunks
+            cc = cnt >> (lg + lk)                                 # words per (peer, chunk)
+            send = self.block[:cnt]
+            send.view(K, G, cc).copy_(loc.view(G, K, cc).transpose(0, 1))     # pack: chunk-major
+            works = [self.comm.all_to_all_async(send[c * G * cc:(c + 1) * G * cc], recv[c * G * cc:(c + 1) * G * cc])
+                     for c in range(K)]
+            for c in range(K):
+                if works[c] is not None:
+                    works[c].wait()
+                be.merkle_chunk(recv[c * G * cc:(c + 1) * G * cc], lg, log_cnt - lk, nodes, m_log - lg, c)
+            be.merkle_finish(nodes, m_log - lg, lk)
+        elif G > 1 or self.comm.force:
             self.comm.all_to_all(loc, recv)                       # chunk q: rank q's j in my block
             if hasattr(be, "merkle_interleaved"):                 # leaf u*G + q = recv[q][u], hashed in place
                 be.merkle_interleaved(recv, lg, m_log - 2 * lg, nodes)
