@@ -148,7 +148,7 @@ def main():
         ctx.set_profiling(())
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": ctx.setup_ms,
                   "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
-                  "units": N * args.steps, "parallelism": "single-gpu"}
+                  "units": N * args.steps, "parallelism": "single-gpu", "host_levels": list(ctx.host_levels)}
         # secondary figure: BASELINE.json configs[1], domain 2^20 LDE + Merkle commit (trace resident -> root on host)
         if args.hash == "sha256" and not args.no_secondary:
             with zk.Context(17, 3, device=local_rank) as c2:
@@ -252,7 +252,9 @@ def main():
             "config": {"workload": f"full prover: LDE + compose + FRI + Merkle, domain 2^{log_n + log_b} "
                                    f"(trace group 2^{log_n}, blow-up {1 << log_b})" + (f" per proof; {result['parallelism']}" if world > 1 else ""),
                        "log_n": log_n, "log_blowup": log_b, "domain": N, "fri_rounds": log_n, "merkle_hash": args.hash,
-                       "parallelism": result["parallelism"]},
+                       "parallelism": result["parallelism"],
+                       # host thread's share of the latency-bound end: [tree-top levels, log2 of the largest host-side FRI layer]
+                       "host_levels": result.get("host_levels")},
             "roofline": roofline,
             "stages": stages,
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],

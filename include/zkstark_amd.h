@@ -85,6 +85,17 @@ int zk_ctx_sync(zk_ctx *ctx);
 int zk_ctx_set_queries(zk_ctx *ctx, uint32_t n_queries);
 /* Selects the Merkle hash of every later zk_merkle_commit / zk_prove* on this context. */
 int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
+/* Division of the latency-bound end of zk_prove* between device and host thread.  A Merkle level is a
+ * chain of dependent hashes (merkle.rs:40-46): ~4.4 us on a GPU wave, ~31 ns per node on a CPU core with
+ * SHA extensions.  With top_log = H > 0 the device builds every SHA-256 tree with more than 2^H leaves
+ * down to its 2^H nodes of depth H and the calling thread hashes the 2^H - 1 nodes above; with
+ * tail_log = T >= H, FRI layers of <= 2^T values (polynomial.rs:385 fold + merkle.rs:14 tree) are
+ * computed by the calling thread as well.  Everything the host built is copied into the device arrays
+ * before the call returns, so zk_layer_read / zk_merkle_path see complete trees.  Default: (8, 9) when
+ * the CPU has SHA extensions, else (0, 0) = all on the device; the stage-by-stage entry points and
+ * the field hash always run on the device.  Results are identical for every setting. */
+int zk_ctx_set_host_levels(zk_ctx *ctx, uint32_t top_log, uint32_t tail_log);
+int zk_ctx_get_host_levels(const zk_ctx *ctx, uint32_t *top_log, uint32_t *tail_log);
 /* The HIP stream every stage is enqueued on (hipStream_t). */
 void *zk_ctx_stream(zk_ctx *ctx);
 

@@ -1,0 +1,38 @@
+// Prints digests from csrc/host_sha.cpp for tests/test_host_sha.py (compared there with hashlib).
+//   host_sha_check <ext:0|1> <depth> <seed>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../zkstark_amd/csrc/host_sha.hpp"
+
+static void hex(const uint32_t w[8]) {
+    for (int i = 0; i < 8; ++i) printf("%08x", w[i]);
+    printf("\n");
+}
+int main(int argc, char** argv) {
+    if (argc != 4) return 2;
+    zk::host_sha_use_extensions(atoi(argv[1]) != 0);
+    printf("%d\n", zk::host_sha_available() ? 1 : 0);
+    const uint32_t depth = (uint32_t)atoi(argv[2]);
+    uint32_t x = (uint32_t)strtoul(argv[3], nullptr, 10);
+    const size_t m = (size_t)1 << depth;
+    std::vector<uint32_t> nodes(8 * (2 * m - 1));
+    for (size_t i = 0; i < m; ++i) {                     // leaves from an LCG; the first few values are edge cases
+        x = x * 1664525u + 1013904223u;
+        uint32_t v = i == 0 ? 0u : i == 1 ? 0xffffffffu : i == 2 ? 3221225472u : x;
+        zk::host_sha_leaf(v, &nodes[8 * (m - 1 + i)]);
+    }
+    zk::host_sha_reduce(nodes.data(), depth);
+    for (size_t i = 0; i < 2 * m - 1; ++i) hex(&nodes[8 * i]);
+    // transcript-style compression chain: state <- compress(state, block) over three blocks
+    uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint32_t blk[16];
+    for (int b = 0; b < 3; ++b) {
+        for (int i = 0; i < 16; ++i) { x = x * 1664525u + 1013904223u; blk[i] = x; }
+        if (b == 2) { blk[8] = 0x80000000u; for (int i = 9; i < 15; ++i) blk[i] = 0; blk[15] = (2 * 64 + 32) * 8; }
+        zk::host_sha_compress(st, blk);
+    }
+    hex(st);
+    return 0;
+}

@@ -384,3 +384,43 @@ def test_compose_and_fold_edge_challenges(zk, orc):
                     nxt = ctx.layer_read(2 + r)
                     assert np.array_equal(nxt, orc.fri_fold_eval(cp if r == 0 else prev, log_n, log_b, r, beta))
                     prev = nxt
+
+
+# ---- device / host division of the latency-bound end (zk_ctx_set_host_levels) ------------------
+@pytest.mark.parametrize("log_n,log_b,levels", [
+    (10, 3, (0, 0)), (10, 3, (8, 9)), (10, 3, (8, 8)), (10, 3, (5, 5)), (10, 3, (6, 10)), (10, 3, (10, 10)), (10, 3, (8, 0)),
+    (10, 3, (3, 3)), (10, 3, (1, 1)), (10, 3, (2, 4)),
+    (5, 3, (8, 9)), (6, 3, (8, 9)), (7, 2, (8, 9)), (6, 2, (8, 8)), (4, 1, (3, 4)), (2, 1, (1, 1)),
+    (15, 3, (8, 9)), (15, 3, (0, 0)), (15, 3, (10, 10)), (16, 2, (7, 9)), (17, 3, (8, 9)), (18, 1, (9, 9)), (11, 5, (8, 9))])
+def test_prover_host_levels_identical(zk, orc, log_n, log_b, levels):
+    """Whatever part of the tree tops / small FRI layers the host thread takes over, the proof is the
+    oracle's, and the device arrays afterwards hold the complete trees and layers (merkle.rs:14-79)."""
+    want = orc.prove(log_n, log_b, want_vectors=False)
+    with zk.Context(log_n, log_b, host_levels=levels) as ctx:
+        assert ctx.host_levels == levels
+        proof = ctx.prove(zk.trace_fibsq((1 << log_n) - 1))
+        assert proof.data == want.proof and proof.state == want.state
+        assert ctx.prove().data == want.proof                         # staging buffers are reusable
+        R = log_n
+        for layer in sorted({0, 1, 2, max(1, R - 7), max(1, R - 6), max(1, R - 5), R, R + 1}):
+            vals = ctx.layer_read(layer)
+            nodes = orc.merkle_build(vals)
+            m = len(vals)
+            idx = sorted({0, 1, 2, 5, 30, 62, 63, 64, 126, 127, 254, 255, 256, 510, 511, 1022, 1023, 2046, m - 2, m - 1, m, 2 * m - 2} & set(range(2 * m - 1)))
+            for i in idx:
+                assert ctx.merkle_node(layer, i) == bytes(nodes[i]), (layer, i)
+            assert ctx.merkle_path(layer, m - 1) == [bytes(h) for h in orc.merkle_trace(nodes, m - 1)]
+    proof.verify(strict=True)
+
+
+def test_host_levels_argument_checks(zk):
+    for bad in ((11, 11), (8, 7), (0, 5), (3, 12)):
+        with pytest.raises(zk.ZkError):
+            zk.Context(6, 2, host_levels=bad).close()
+    # the field hash always builds on the device, whatever the setting
+    with zk.Context(10, 3, hash="field", host_levels=(8, 9)) as ctx:
+        p = ctx.prove(zk.trace_fibsq(1023))
+    with zk.Context(10, 3, hash="field", host_levels=(0, 0)) as ctx:
+        q = ctx.prove(zk.trace_fibsq(1023))
+    assert p.data == q.data
+    p.verify(strict=True)

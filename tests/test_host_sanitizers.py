@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def checker(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("san") / "host_sanitizer_check")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           os.path.join(ROOT, "tests", "host_sanitizer_check.cpp"), "-o", exe])
+                           os.path.join(ROOT, "tests", "host_sanitizer_check.cpp"),
+                           os.path.join(ROOT, "zkstark_amd", "csrc", "host_sha.cpp"), "-o", exe])
     return exe
 
 

@@ -482,7 +482,7 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
 // it instead of paying a blit kernel + stream synchronisation per commitment.
 template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t j,
-                                                               uint32_t* mailbox, uint32_t seq, size_t off) {
+                                                               MailArgs mail, size_t off) {
     extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2], then the 16 KiB schedule exchange
     uint32_t* xch = reinterpret_cast<uint32_t*>(lvl + ((size_t)2 << j));
     const uint32_t tid = threadIdx.x;
@@ -578,11 +578,33 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
         __syncthreads();
     }
-    if (mailbox && depth_in == j && off == 0 && tid == 0) {
-        Digest r = lds_digest(&lvl[0]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) __hip_atomic_store(&mailbox[2 + i], r.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mailbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // The launch that reaches depth mail.top posts its 2^top digests (and, on request, the layer values) to the
+    // host: small PCIe writes are slow, so the workgroup that finishes last copies everything with wide stores.
+    if (mail.mailbox && depth_in - j == mail.top && off == 0) {
+        __shared__ uint32_t is_last;
+        if (tid == 0) {
+            uint32_t last = 1;
+            if (gridDim.x > 1) {
+                // release: this workgroup's digest (and values) are out; acquire: so are everybody else's
+                last = __hip_atomic_fetch_add(mail.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+                if (last) __hip_atomic_store(mail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            is_last = last;
+        }
+        __syncthreads();
+        if (is_last) {
+            const uint4* sq = reinterpret_cast<const uint4*>(nodes + (((size_t)1 << mail.top) - 1) * 8);
+            uint4* dq = reinterpret_cast<uint4*>(mail.mailbox + kMailDigests);
+            for (uint32_t i = tid; i < (2u << mail.top); i += kWgThreads) dq[i] = sq[i];
+            if (mail.dump_src) {
+                const uint4* sv = reinterpret_cast<const uint4*>(mail.dump_src);
+                uint4* dv = reinterpret_cast<uint4*>(mail.mailbox + mail.vals_off);
+                for (uint32_t i = tid; i < (1u << mail.dump_log) / 4; i += kWgThreads) dv[i] = sv[i];
+            }
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&mail.mailbox[0], mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -630,7 +652,7 @@ static uint32_t merkle_latency_log() {            // ZK_MERKLE_LATENCY_LOG overr
 // A whole tree is chunk 0 with log_sub = log_m.
 template <class SRC>
 static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
-                                 uint32_t* mailbox, uint32_t seq, int hash, uint32_t log_sub = 0xffffffffu, size_t chunk = 0,
+                                 const MailArgs& mail_in, int hash, uint32_t log_sub = 0xffffffffu, size_t chunk = 0,
                                  bool leaf_mode = true, bool throughput_only = false) {
     if (hash) {
         hipError_t e = ensure_fieldhash_consts();
@@ -666,37 +688,43 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
         depth -= k;
     }
     if (throughput_only) return hipGetLastError();
+    // top > 0 (whole trees only): the build ends at depth `top`, whose 2^top digests go to the mailbox slots
+    // and are finished by the host (host_sha.hpp)
+    MailArgs mail = mail_in;
+    if (stop != 0 || mail.top >= log_m) mail.top = 0;
+    const uint32_t end = stop == 0 ? mail.top : stop;
     do {
         // split the remaining levels evenly over the launches (each <= kWgMaxLog)
         uint32_t span = depth - stop;
-        uint32_t launches = (span + kWgMaxLog - 1) / kWgMaxLog;
+        uint32_t levels = depth - end;
+        uint32_t launches = (levels + kWgMaxLog - 1) / kWgMaxLog;
         if (launches == 0) launches = 1;
-        uint32_t j = (span + launches - 1) / launches;
+        uint32_t j = (levels + launches - 1) / launches;
         uint32_t blocks = 1u << (span - j);
         size_t sh = ((size_t)2 << j) * sizeof(uint4) + 2 * 16 * 128 * sizeof(uint32_t);
         ScopedKernelTimer tm(prof, K_MERKLE_TOP, first_bytes(merkle_bytes(leaf, span, j)), s, merkle_ops(leaf, span, j, hash));
         if (hash) {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq, off_at(depth));
-            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq, off_at(depth));
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mail, off_at(depth));
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mail, off_at(depth));
         } else {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mailbox, seq, off_at(depth));
-            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mailbox, seq, off_at(depth));
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mail, off_at(depth));
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mail, off_at(depth));
         }
         leaf = false;
         depth -= j;
-    } while (depth > stop);
+    } while (depth > end);
     return hipGetLastError();
 }
 
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
-                               uint32_t* mailbox, uint32_t seq, int hash) {
-    return merkle_build_t(PlainSrc{vals}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, mailbox, seq, hash);
+                               const MailArgs& mail, int hash) {
+    return merkle_build_t(PlainSrc{vals}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, mail, hash);
 }
 // commitment of a block whose leaves are still in all-to-all order (no interleave pass, no block buffer)
 hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, hipStream_t s,
                                            Profiler* prof, int hash) {
     uint32_t log_m = log_parts + log_cnt;
-    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, nullptr, 0, hash);
+    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, MailArgs{}, hash);
 }
 // One chunk (1 / 2^log_chunks of the leaves, still in all-to-all order in its own receive buffer) of a
 // tree over 2^log_m leaves: levels up to the chunk root.  launch_merkle_finish joins the chunk roots.
@@ -710,7 +738,7 @@ hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, u
                                      uint32_t chunk, hipStream_t s, Profiler* prof, int hash) {
     uint32_t log_sub = log_parts + log_cnt;
     bool tp_only = chunk_handover_depth(log_m, log_m - log_sub) != log_m - log_sub;
-    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_sub), log_m, nodes, s, prof, nullptr, 0, hash,
+    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_sub), log_m, nodes, s, prof, MailArgs{}, hash,
                           log_sub, chunk, true, tp_only);
 }
 // After every chunk of a 2^log_m-leaf tree (2^log_chunks chunks) has been built down to the switch depth:
@@ -719,16 +747,38 @@ hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_ch
     const uint32_t start = chunk_handover_depth(log_m, log_chunks);   // depth the chunk builds stopped at
     if (start == 0) return hipSuccess;
     // the nodes at depth `start` exist: inner mode over a "tree" of 2^start inputs shares the top of the heap
-    return merkle_build_t(PlainSrc{nullptr}, 0.0, start, nodes, s, prof, nullptr, 0, hash, start, 0, false);
+    return merkle_build_t(PlainSrc{nullptr}, 0.0, start, nodes, s, prof, MailArgs{}, hash, start, 0, false);
 }
 // fold + commit of the folded layer (a.out receives it): one pass
-hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {
+hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, const MailArgs& mail, int hash) {
     uint32_t log_out = a.log_m - 1;
-    return merkle_build_t(FoldSrc{a}, 12.0 * (double)((size_t)1 << log_out), log_out, nodes, s, prof, mailbox, seq, hash);
+    return merkle_build_t(FoldSrc{a}, 12.0 * (double)((size_t)1 << log_out), log_out, nodes, s, prof, mail, hash);
 }
 // composition + commit of cp layer 0 (a.cp receives it): one pass
-hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, uint32_t* mailbox, uint32_t seq, int hash) {
-    return merkle_build_t(ComposeSrc{a}, 8.0 * (double)((size_t)1 << a.logN), a.logN, nodes, s, prof, mailbox, seq, hash);
+hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, const MailArgs& mail, int hash) {
+    return merkle_build_t(ComposeSrc{a}, 8.0 * (double)((size_t)1 << a.logN), a.logN, nodes, s, prof, mail, hash);
+}
+
+// Copies host-built pieces (tree tops, small layers) from the mapped staging buffer into the device
+// arrays so that the device state is complete after a proof (zk_merkle_path, zk_layer_read).
+__global__ __launch_bounds__(1024) void scatter_kernel(const uint32_t* stage, const ScatterSeg* segs, uint32_t* trees, uint32_t* layers) {
+    const ScatterSeg sg = segs[blockIdx.x];
+    uint32_t* dst = (sg.kind ? layers : trees) + sg.dst;
+    const uint32_t* src = stage + sg.src;
+    if (((sg.src | sg.dst | sg.words) & 3) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (uint32_t i = threadIdx.x; i < sg.words / 4; i += blockDim.x) d4[i] = s4[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < sg.words; i += blockDim.x) dst[i] = src[i];
+    }
+}
+hipError_t launch_scatter(const uint32_t* stage, const ScatterSeg* segs, uint32_t count, double words, uint32_t* trees, uint32_t* layers,
+                          hipStream_t s, Profiler* prof) {
+    if (!count) return hipSuccess;
+    ScopedKernelTimer tm(prof, K_GATHER, 8.0 * words, s);
+    hipLaunchKernelGGL(scatter_kernel, dim3(count), dim3(1024), 0, s, stage, segs, trees, layers);
+    return hipGetLastError();
 }
 
 // ===========================================================================

@@ -133,10 +133,26 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof = nu
 
 // Merkle tree over m = 2^log_m u32 leaves.  nodes: (2m-1) * 8 words, heap order
 // (merkle.rs:14-51), each node the eight SHA-256 state words.
-// mailbox (optional): 10 words of host-mapped memory; word 0 <- seq after words 2..9 <- root state words.
+// mail (optional): where the result of the build is posted for the host, see MailArgs.
 // hash: 0 = SHA-256 (the reference, merkle.rs:1-2), 1 = field-native hash (fieldhash.hpp, configs[4]).
+// The commit -> challenge hand-off.  mailbox is host-mapped memory: word 0 <- seq (last), words
+// kMailDigests.. <- the 2^top digests of depth `top` (top = 0: the root; the build stops at that depth and
+// the host finishes the tree, host_sha.hpp), then, if dump_src is set, 2^dump_log leaf values.  The
+// workgroup that finishes last copies everything in one burst of wide stores (counter: one zeroed device word).
+constexpr uint32_t kMailDigests = 16;
+struct MailArgs {
+    uint32_t* mailbox = nullptr;
+    uint32_t seq = 0, top = 0;
+    uint32_t* counter = nullptr;
+    const uint32_t* dump_src = nullptr;   // device pointer to the layer the tree is built over
+    uint32_t dump_log = 0;
+    uint32_t vals_off = 0;                // word offset of the value area inside the mailbox
+};
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
-                               uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
+                               const MailArgs& mail = MailArgs{}, int hash = 0);
+struct ScatterSeg { uint64_t src, dst; uint32_t words, kind; };   // kind 0: into the trees array, 1: into the layers array
+hipError_t launch_scatter(const uint32_t* stage, const ScatterSeg* segs, uint32_t count, double words, uint32_t* trees, uint32_t* layers,
+                          hipStream_t s, Profiler* prof = nullptr);
 
 hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, hipStream_t s,
                                            Profiler* prof = nullptr, int hash = 0);
@@ -145,9 +161,9 @@ hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, u
 hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof = nullptr, int hash = 0);
 // Fused producer + commitment: the layer is computed, stored and leaf-hashed in one pass.
 hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
-                              uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
+                              const MailArgs& mail = MailArgs{}, int hash = 0);
 hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
-                                 uint32_t* mailbox = nullptr, uint32_t seq = 0, int hash = 0);
+                                 const MailArgs& mail = MailArgs{}, int hash = 0);
 
 // batch traces of prover.rs:32-39, one lane per trace: out[t*count + i]
 hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s);

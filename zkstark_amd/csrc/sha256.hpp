@@ -14,6 +14,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "host_sha.hpp"
+
 #if defined(__HIPCC__)
 #define ZK_SHA_HD __host__ __device__ __forceinline__
 #else
@@ -149,7 +151,7 @@ struct Sha256 {
         uint32_t w[16];
         for (int i = 0; i < 16; ++i)
             w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
-        sha256_compress(st, w);
+        host_sha_compress(st, w);                  // SHA extensions when the CPU has them (host_sha.cpp)
     }
     void update(const void* data, size_t n) {
         const uint8_t* m = (const uint8_t*)data;

@@ -19,6 +19,7 @@
 #include "kernels.hpp"
 #include "sha256.hpp"
 #include "transcript.hpp"
+#include "host_sha.hpp"
 
 using namespace zk;
 
@@ -47,6 +48,9 @@ int fail(int code, const char* fmt, ...) {
 // The size-2^log_m transform is split into radix-2^bits[d] passes, d = 0 slowest
 // storage digit.  DIF (inverse) runs d = 0 .. nd-1, DIT (forward) nd-1 .. 0.
 constexpr uint32_t kMaxQueries = 64;
+constexpr uint32_t kMaxHostLog = 10;                         // host_top, host_tail <= 10
+constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // after the digests of depth host_top
+constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail
 constexpr uint32_t kTileLog = 13;      // 8192 words = 32 KiB per workgroup tile
 constexpr uint32_t kMaxRadixLog = 8;
 
@@ -307,9 +311,23 @@ struct zk_ctx {
     uint64_t* h_gather_off = nullptr;   // pinned
     uint32_t* h_gather_out = nullptr;   // pinned
     uint32_t* h_small = nullptr;        // pinned: root words + last layer
-    uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: [seq, -, root words 0..7]
+    uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: layout in kernels.hpp (MailArgs)
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
+    uint32_t* d_counter = nullptr;      // one zeroed word: workgroups of a commit launch that are done
     uint32_t mail_seq = 0;
+    // Host-finished pieces of the one-call prover (host_sha.hpp): the top `host_top` levels of every tree
+    // with more than 2^host_top leaves, and whole FRI layers of <= 2^host_tail values (fold + tree).
+    uint32_t host_top = 0, host_tail = 0;
+    uint32_t* h_stage = nullptr;        // pinned, device-mapped: host-built nodes / values waiting for scatter_kernel
+    uint32_t* d_stage = nullptr;
+    size_t stage_words = 0, stage_used = 0;
+    ScatterSeg* h_segs = nullptr;       // at the end of h_stage
+    ScatterSeg* d_segs = nullptr;
+    uint32_t n_segs = 0;
+    double seg_words = 0;
+    std::vector<uint32_t> tail_vals;    // current host-side FRI layer (valid when tail_log != 0)
+    uint32_t tail_log = 0;              // log2 size of tail_vals
+    bool tail_have = false;             // false: the current FRI layer lives on the device only
     bool tail = false;                  // FRI-tail context (zk_tail_*): no trace / LDE / composition
     uint32_t queries = 1;               // decommitment queries (1 = the reference, prover.rs:263)
     int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
@@ -361,11 +379,34 @@ int do_lde(zk_ctx* c) {
     return rc;
 }
 
-// Builds tree `layer`; the launch that produces the root also posts it to the host mailbox.
-int do_merkle(zk_ctx* c, uint32_t layer) {
-    c->mail_seq += 1;
-    HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer),
-                               c->d_trees + c->tree_off[layer], c->stream, prof_of(c), c->d_mailbox, c->mail_seq, c->hash));
+// How much of tree `tree` the host finishes: the top `host_top` levels of SHA-256 trees larger than that.
+uint32_t top_of(const zk_ctx* c, uint32_t tree) {
+    return (c->hash == 0 && c->host_top && layer_log(c, tree) > c->host_top) ? c->host_top : 0;
+}
+// What the commit launch of `tree` posts to the host.  host = true (one-call flows): the digests of depth
+// host_top instead of the root, and for the layer with 2^(host_tail+1) values the values too -- the host
+// folds on from there.
+MailArgs mail_of(zk_ctx* c, uint32_t tree, bool host) {
+    MailArgs m;
+    m.mailbox = c->d_mailbox;
+    m.seq = ++c->mail_seq;
+    m.counter = c->d_counter;
+    m.top = host ? top_of(c, tree) : 0;
+    if (m.top && c->host_tail && tree >= 1 && layer_log(c, tree) == c->host_tail + 1) {
+        m.dump_src = c->d_layers + c->layer_off[tree];
+        m.dump_log = c->host_tail + 1;
+        m.vals_off = (uint32_t)kMailValsOff;
+        c->tail_log = m.dump_log;                         // tail_vals is filled by read_commit
+        c->tail_have = true;
+    }
+    return m;
+}
+
+// Builds tree `layer`; the launch that reaches the hand-over depth posts its digests to the host mailbox.
+// host = false: the whole tree on the device (the stage-by-stage API).
+int do_merkle(zk_ctx* c, uint32_t layer, bool host = false) {
+    HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer), c->d_trees + c->tree_off[layer], c->stream,
+                               prof_of(c), mail_of(c, layer, host), c->hash));
     return ZK_OK;
 }
 
@@ -374,37 +415,130 @@ int do_compose_commit(zk_ctx* c, const uint32_t alpha_raw[3]) {
     ComposeArgs a;
     int rc = compose_args(c->dom, c->d_layers + c->layer_off[0], c->d_layers + c->layer_off[1], c->first, c->last, alpha_raw, a);
     if (rc) return rc;
-    c->mail_seq += 1;
-    HIPCHK(launch_compose_merkle(a, c->d_trees + c->tree_off[1], c->stream, prof_of(c), c->d_mailbox, c->mail_seq, c->hash));
+    HIPCHK(launch_compose_merkle(a, c->d_trees + c->tree_off[1], c->stream, prof_of(c), mail_of(c, 1, true), c->hash));
     return ZK_OK;
 }
 int do_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
     FoldArgs a;
     int rc = fold_args(c->dom, c->d_layers + c->layer_off[1 + round], c->d_layers + c->layer_off[2 + round], c->L - round, round, beta_raw, a);
     if (rc) return rc;
-    c->mail_seq += 1;
-    HIPCHK(launch_fold_merkle(a, c->d_trees + c->tree_off[2 + round], c->stream, prof_of(c), c->d_mailbox, c->mail_seq, c->hash));
+    HIPCHK(launch_fold_merkle(a, c->d_trees + c->tree_off[2 + round], c->stream, prof_of(c), mail_of(c, 2 + round, true), c->hash));
     return ZK_OK;
 }
 
-// Waits for the root posted by the last do_merkle (polling host-coherent memory: no blit kernel, no
-// stream synchronisation on the commit -> challenge critical path).
-int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
-    (void)tree;
+// Waits until the mailbox carries the sequence number of the last commit launch (polling host-coherent
+// memory: no blit kernel, no stream synchronisation on the commit -> challenge path).
+int wait_mail(zk_ctx* c) {
     const uint32_t want = c->mail_seq;
+    const uint32_t* flag = c->h_mailbox;
     auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
-    while (__atomic_load_n(&c->h_mailbox[0], __ATOMIC_ACQUIRE) != want) {
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
         if ((++spins & 0xFFFF) == 0) {
-            if (hipStreamQuery(c->stream) == hipSuccess && __atomic_load_n(&c->h_mailbox[0], __ATOMIC_ACQUIRE) != want)
-                return fail(ZK_ERR_HIP, "merkle root was never posted (stream drained)");
+            if (hipStreamQuery(c->stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
+                return fail(ZK_ERR_HIP, "merkle digests were never posted (stream drained)");
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-                return fail(ZK_ERR_HIP, "timed out waiting for a merkle root");
+                return fail(ZK_ERR_HIP, "timed out waiting for merkle digests");
         }
     }
-    uint32_t w[8];
-    for (int i = 0; i < 8; ++i) w[i] = __atomic_load_n(&c->h_mailbox[2 + i], __ATOMIC_RELAXED);
-    digest_words_to_bytes(w, out);
+    return ZK_OK;
+}
+
+// Root posted by a whole-tree build.
+int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
+    (void)tree;
+    int rc = wait_mail(c);
+    if (rc) return rc;
+    digest_words_to_bytes(c->h_mailbox + kMailDigests, out);
+    return ZK_OK;
+}
+
+uint32_t* stage_alloc(zk_ctx* c, size_t words) {
+    if (c->stage_used + words > c->stage_words) return nullptr;
+    uint32_t* p = c->h_stage + c->stage_used;
+    c->stage_used += (words + 7) & ~(size_t)7;
+    return p;
+}
+int stage_seg(zk_ctx* c, const uint32_t* src, size_t dst, size_t words, uint32_t kind) {
+    if (c->n_segs >= 4 * 34) return fail(ZK_ERR_STATE, "scatter segment table full");
+    c->h_segs[c->n_segs++] = ScatterSeg{(uint64_t)(src - c->h_stage), (uint64_t)dst, (uint32_t)words, kind};
+    c->seg_words += (double)words;
+    return ZK_OK;
+}
+
+// Result of the commit launch of `tree`: either the root itself, or the 2^host_top digests of depth
+// host_top, which this thread reduces to the root (merkle.rs:40-46) and keeps for the scatter.
+int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
+    const uint32_t H = top_of(c, tree);
+    if (!H) return read_root(c, tree, root);
+    const size_t cnt = (size_t)1 << H;
+    uint32_t* nodes = stage_alloc(c, (2 * cnt - 1) * 8);
+    if (!nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
+    int rc = wait_mail(c);
+    if (rc) return rc;
+    memcpy(nodes + 8 * (cnt - 1), c->h_mailbox + kMailDigests, cnt * 32);
+    host_sha_reduce(nodes, H);
+    digest_words_to_bytes(nodes, root);
+    if (c->tail_have && c->tail_log == layer_log(c, tree) && tree >= 1) {     // this launch dumped its leaves (mail_of)
+        c->tail_vals.assign(c->h_mailbox + kMailValsOff, c->h_mailbox + kMailValsOff + ((size_t)1 << c->tail_log));
+    }
+    return stage_seg(c, nodes, c->tree_off[tree], (cnt - 1) * 8, 0);
+}
+
+// FRI round `round` on the host: fold tail_vals with beta (the formula of fold_at, kernels.hip), hash the
+// new layer's tree (merkle.rs:14-51); values and nodes are staged for the device copy.
+int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[32]) {
+    const uint32_t log_out = c->L - round - 1;
+    const size_t half = (size_t)1 << log_out;
+    uint32_t* vals = stage_alloc(c, half);
+    uint32_t* nodes = stage_alloc(c, (2 * half - 1) * 8);
+    if (!vals || !nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
+    const zk_dom* d = c->dom;
+    const uint32_t inv2 = invmod(2);
+    const uint32_t cc = mulmod(mulmod(beta_raw % P, invmod(powmod(d->shift, (uint64_t)1 << round))), inv2);   // beta / (2 w^(2^r))
+    const uint32_t step = powmod(invmod(d->h), (uint64_t)1 << round);                                        // h^(-2^r)
+    const uint32_t* in = c->tail_vals.data();
+    uint32_t xinv = 1;
+    for (size_t i = 0; i < half; ++i) {
+        uint32_t u = in[i], v = in[i + half];
+        vals[i] = add(mulmod(add(u, v), inv2), mulmod(mulmod(sub(u, v), xinv), cc));
+        xinv = mulmod(xinv, step);
+    }
+    for (size_t i = 0; i < half; ++i) host_sha_leaf(vals[i], nodes + 8 * (half - 1 + i));
+    host_sha_reduce(nodes, log_out);
+    digest_words_to_bytes(nodes, root);
+    c->tail_vals.assign(vals, vals + half);
+    c->tail_log = log_out;
+    int rc = stage_seg(c, vals, c->layer_off[2 + round], half, 1);
+    if (!rc) rc = stage_seg(c, nodes, c->tree_off[2 + round], (2 * half - 1) * 8, 0);
+    return rc;
+}
+
+// One FRI round of the one-call flows: on the host once the layers are small and present there.
+int fri_round_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[32]) {
+    if (c->tail_have && c->tail_log == c->L - round && c->L - round - 1 <= c->host_tail) return host_fold_commit(c, round, beta_raw, root);
+    int rc = do_fold_commit(c, round, beta_raw);
+    return rc ? rc : read_commit(c, 2 + round, root);
+}
+void begin_proof(zk_ctx* c) { c->stage_used = 0; c->n_segs = 0; c->seg_words = 0; c->tail_log = 0; c->tail_have = false; }
+// Device copies of everything the host built, stream-ordered before any later read of trees / layers.
+int flush_host_parts(zk_ctx* c) {
+    HIPCHK(launch_scatter(c->d_stage, c->d_segs, c->n_segs, c->seg_words, c->d_trees, c->d_layers, c->stream, prof_of(c)));
+    c->n_segs = 0;
+    return ZK_OK;
+}
+// B evaluations of a degree-0 polynomial (prover.rs:238, :251) -> the free term (prover.rs:254)
+int last_layer_value(zk_ctx* c, uint32_t* out) {
+    const uint32_t* v;
+    if (c->tail_have && c->tail_log == c->log_b) v = c->tail_vals.data();
+    else {
+        HIPCHK(hipMemcpyAsync(c->h_small, c->d_layers + c->layer_off[1 + c->R], c->B * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        v = c->h_small;
+    }
+    for (size_t i = 1; i < c->B; ++i)
+        if (v[i] != v[0]) return fail(ZK_ERR_CHECK, "last FRI layer is not constant (prover.rs:238): trace does not satisfy the constraints");
+    *out = v[0];
     return ZK_OK;
 }
 
@@ -445,32 +579,29 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     int rc;
     memset(&c->info, 0, sizeof c->info);
     c->info.public_last = c->last;
+    begin_proof(c);
     if ((rc = do_lde(c))) return rc;                      // prover.rs:60-70
-    if ((rc = do_merkle(c, 0))) return rc;                // prover.rs:81
-    if ((rc = read_root(c, 0, root))) return rc;
+    if ((rc = do_merkle(c, 0, true))) return rc;          // prover.rs:81
+    if ((rc = read_commit(c, 0, root))) return rc;
     ch.commit_hash(root);                                 // prover.rs:85
     memcpy(c->info.roots[0], root, 32);
     uint32_t alpha[3];
     for (int i = 0; i < 3; ++i) alpha[i] = c->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
     if ((rc = do_compose_commit(c, alpha))) return rc;    // prover.rs:166-176 (composition fused into the leaf hashing)
-    if ((rc = read_root(c, 1, root))) return rc;
+    if ((rc = read_commit(c, 1, root))) return rc;
     ch.commit_hash(root);                                 // prover.rs:180
     memcpy(c->info.roots[1], root, 32);
     for (uint32_t r = 0; r < R; ++r) {                    // prover.rs:198-225
         uint32_t beta = c->info.beta_raw[r] = ch.get_u32();   // prover.rs:200
-        if ((rc = do_fold_commit(c, r, beta))) return rc;  // prover.rs:201-214 (fold fused into the leaf hashing)
-        if ((rc = read_root(c, 2 + r, root))) return rc;
+        if ((rc = fri_round_commit(c, r, beta, root))) return rc;   // prover.rs:201-214 (fold fused into the leaf hashing)
         ch.commit_hash(root);                             // prover.rs:224
         memcpy(c->info.roots[2 + r], root, 32);
     }
     lap("lde .. last root");
     // last layer: B evaluations of a degree-0 polynomial (prover.rs:238, :251); free term prover.rs:254
-    HIPCHK(hipMemcpyAsync(c->h_small, c->d_layers + c->layer_off[1 + R], B * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (size_t i = 1; i < B; ++i)
-        if (c->h_small[i] != c->h_small[0])
-            return fail(ZK_ERR_CHECK, "last FRI layer is not constant (prover.rs:238): trace does not satisfy the constraints");
-    uint32_t free_term = c->info.free_term = c->h_small[0];
+    uint32_t free_term = 0;
+    if ((rc = last_layer_value(c, &free_term))) return rc;
+    c->info.free_term = free_term;
     ch.commit_u32(free_term);                             // prover.rs:254
     const uint32_t Q = c->queries;
     uint32_t qraws[64];
@@ -503,6 +634,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
         memcpy(c->h_gather_off, voff.data(), nv * 8);
         memcpy(c->h_gather_off + nv, doff.data(), ndg * 8);
         HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, (nv + ndg) * 8, hipMemcpyHostToDevice, c->stream));
+        if ((rc = flush_host_parts(c))) return rc;
         HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream, prof_of(c)));
         HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream, prof_of(c)));
         HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -621,9 +753,26 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8));
     HIPCHK_C(hipHostMalloc((void**)&c->h_gather_out, c->gather_cap * 32));
     HIPCHK_C(hipHostMalloc((void**)&c->h_small, 4096));
-    HIPCHK_C(hipHostMalloc((void**)&c->h_mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_mailbox, 0, 64);
+    const size_t mail_bytes = kMailWords * 4;
+    if ((rc = dmalloc(c, &c->d_counter, 64))) return bail(rc);
+    HIPCHK_C(hipMemsetAsync(c->d_counter, 0, 64, c->stream));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_mailbox, mail_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_mailbox, 0, mail_bytes);
     HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_mailbox, 0));
+    // staging for host-built tree tops and tail layers: one top per tree, the tail layers and their trees, the segment table
+    c->stage_words = (size_t)(c->R + 2) * ((size_t)16 << kMaxHostLog) + ((size_t)64 << kMaxHostLog);
+    const size_t seg_bytes = 4 * 34 * sizeof(ScatterSeg);
+    HIPCHK_C(hipHostMalloc((void**)&c->h_stage, c->stage_words * 4 + seg_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_stage, c->h_stage, 0));
+    c->h_segs = reinterpret_cast<ScatterSeg*>(c->h_stage + c->stage_words);
+    c->d_segs = reinterpret_cast<ScatterSeg*>(c->d_stage + c->stage_words);
+    if (host_sha_available()) {            // without the SHA extensions the device builds every tree to the root
+        c->host_top = 8;
+        c->host_tail = 9;
+        if (const char* e = getenv("ZK_HOST_TOP_LOG")) c->host_top = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 8;
+        if (const char* e = getenv("ZK_HOST_TAIL_LOG")) c->host_tail = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 9;
+        if (!c->host_top || c->host_tail < c->host_top) c->host_tail = 0;
+    }
 #undef HIPCHK_C
     c->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = c;
@@ -639,12 +788,14 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (c->d_coef) (void)hipFree(c->d_coef);
     if (c->d_layers) (void)hipFree(c->d_layers);
     if (c->d_trees) (void)hipFree(c->d_trees);
+    if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->d_gather_off) (void)hipFree(c->d_gather_off);
     if (c->d_gather_out) (void)hipFree(c->d_gather_out);
     if (c->h_gather_off) (void)hipHostFree(c->h_gather_off);
     if (c->h_gather_out) (void)hipHostFree(c->h_gather_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_mailbox) (void)hipHostFree(c->h_mailbox);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     collect_kernel_stats(c);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -667,6 +818,20 @@ int zk_ctx_set_queries(zk_ctx* c, uint32_t n_queries) {
     return ZK_OK;
 }
 
+int zk_ctx_set_host_levels(zk_ctx* c, uint32_t top_log, uint32_t tail_log) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    if (top_log > kMaxHostLog || tail_log > kMaxHostLog || (tail_log && tail_log < top_log) || (tail_log && !top_log))
+        return fail(ZK_ERR_INVALID, "zk_ctx_set_host_levels: need top_log <= tail_log <= %u (or tail_log = 0)", kMaxHostLog);
+    c->host_top = top_log;
+    c->host_tail = tail_log;
+    return ZK_OK;
+}
+int zk_ctx_get_host_levels(const zk_ctx* c, uint32_t* top_log, uint32_t* tail_log) {
+    if (!c || !top_log || !tail_log) return fail(ZK_ERR_INVALID, "zk_ctx_get_host_levels: null argument");
+    *top_log = c->host_top;
+    *tail_log = c->host_tail;
+    return ZK_OK;
+}
 int zk_ctx_set_hash(zk_ctx* c, int hash_kind) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
     if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_ctx_set_hash: unknown hash %d", hash_kind);
@@ -892,24 +1057,19 @@ int zk_tail_run(zk_ctx* c, const uint32_t* d_layer0, void* src_stream, zk_channe
     Channel& ch = chan->ch;
     uint8_t root[32];
     int rc;
-    if ((rc = do_merkle(c, 1))) return rc;                             // prover.rs:214 for the handed-over layer
-    if ((rc = read_root(c, 1, root))) return rc;
+    begin_proof(c);
+    if ((rc = do_merkle(c, 1, true))) return rc;                       // prover.rs:214 for the handed-over layer
+    if ((rc = read_commit(c, 1, root))) return rc;
     ch.commit_hash(root);                                              // prover.rs:224
     memcpy(roots_out, root, 32);
     for (uint32_t r = 0; r < c->R; ++r) {                              // prover.rs:198-225
         uint32_t beta = betas_out[r] = ch.get_u32();
-        if ((rc = do_fold_commit(c, r, beta))) return rc;
-        if ((rc = read_root(c, 2 + r, root))) return rc;
+        if ((rc = fri_round_commit(c, r, beta, root))) return rc;
         ch.commit_hash(root);
         memcpy(roots_out + 32 * (r + 1), root, 32);
     }
-    HIPCHK(hipMemcpyAsync(c->h_small, c->d_layers + c->layer_off[1 + c->R], c->B * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (size_t i = 1; i < c->B; ++i)
-        if (c->h_small[i] != c->h_small[0])
-            return fail(ZK_ERR_CHECK, "last FRI layer is not constant (prover.rs:238)");
-    *free_term_out = c->h_small[0];
-    return ZK_OK;
+    if ((rc = last_layer_value(c, free_term_out))) return rc;
+    return flush_host_parts(c);                                        // zk_tail_open reads the device arrays
 }
 
 // Openings of the tail layers for global query index x (prover.rs:280-289): for tail layer i < R,
@@ -1054,7 +1214,7 @@ int zk_dev_gather(const uint32_t* d_src, const uint64_t* d_offsets, uint32_t cou
 // ---- stand-alone primitives --------------------------------------------------------
 int zk_dev_merkle_build_ex(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream, int hash_kind) {
     if (!d_vals || !d_nodes || log_m > 30 || (hash_kind != 0 && hash_kind != 1)) return fail(ZK_ERR_INVALID, "zk_dev_merkle_build: bad argument");
-    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream, dev_prof(), nullptr, 0, hash_kind));
+    HIPCHK(launch_merkle_build(d_vals, log_m, d_nodes, (hipStream_t)stream, dev_prof(), MailArgs{}, hash_kind));
     return ZK_OK;
 }
 int zk_dev_merkle_build_interleaved(const uint32_t* d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* d_nodes, void* stream, int hash_kind) {
@@ -1111,7 +1271,7 @@ int zk_merkle_build_host_ex(int device, const uint32_t* vals, size_t m, uint8_t*
     std::vector<uint32_t> host(words);
     do {
         if (hipMemcpy(d_vals, vals, m * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "H2D failed"); break; }
-        if (launch_merkle_build(d_vals, log_m, d_nodes, nullptr, nullptr, nullptr, 0, hash_kind) != hipSuccess) { rc = fail(ZK_ERR_HIP, "merkle launch failed"); break; }
+        if (launch_merkle_build(d_vals, log_m, d_nodes, nullptr, nullptr, MailArgs{}, hash_kind) != hipSuccess) { rc = fail(ZK_ERR_HIP, "merkle launch failed"); break; }
         if (hipMemcpy(host.data(), d_nodes, words * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "D2H failed: %s", hipGetErrorString(hipGetLastError())); break; }
     } while (0);
     (void)hipFree(d_vals); (void)hipFree(d_nodes);

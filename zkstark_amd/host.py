@@ -193,7 +193,8 @@ def lde(trace, log_n, log_blowup, device=0):
 class Context:
     """Device-resident prover state for one (log_n, log_blowup): zk_ctx."""
 
-    def __init__(self, log_n=10, log_blowup=3, device=0, hash="sha256", queries=1):
+    def __init__(self, log_n=10, log_blowup=3, device=0, hash="sha256", queries=1, host_levels=None):
+        """host_levels: (top_log, tail_log) of zk_ctx_set_host_levels; None = the library default."""
         self.log_n, self.log_blowup, self.device, self.hash, self.queries = log_n, log_blowup, device, hash, queries
         self.n, self.B = 1 << log_n, 1 << log_blowup
         self.N, self.rounds = self.n * self.B, log_n
@@ -203,6 +204,8 @@ class Context:
             check(_lib.load().zk_ctx_set_hash(self._h, HASHES[hash]))
         if queries != 1:
             check(_lib.load().zk_ctx_set_queries(self._h, queries))
+        if host_levels is not None:
+            check(_lib.load().zk_ctx_set_host_levels(self._h, host_levels[0], host_levels[1]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -220,6 +223,12 @@ class Context:
     def device_bytes(self): return _lib.load().zk_ctx_device_bytes(self._h)
     @property
     def stream(self): return _lib.load().zk_ctx_stream(self._h)
+
+    @property
+    def host_levels(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(_lib.load().zk_ctx_get_host_levels(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def sync(self): check(_lib.load().zk_ctx_sync(self._h))
     def set_profiling(self, classes=()):
