@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, log_n, log_b, min_chunk_log, q):
+def _worker(rank, world, port, log_n, log_b, min_chunk_log, q, min_layer_log=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,7 +34,7 @@ def _worker(rank, world, port, log_n, log_b, min_chunk_log, q):
         from sharded_testlib import OracleBackend
         from zkstark_amd import sharded
         be = OracleBackend()
-        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(), be, min_chunk_log=min_chunk_log)
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(), be, min_chunk_log=min_chunk_log, min_layer_log=min_layer_log)
         sp.trace_upload(oracle.trace_fibsq((1 << log_n) - 1))
         proof = sp.prove()
         q.put((rank, proof.data, proof.state, sp.n_sharded, dict(be.calls), [r.hex() for r in sp.transcript["roots"]]))
@@ -42,11 +42,11 @@ def _worker(rank, world, port, log_n, log_b, min_chunk_log, q):
         dist.destroy_process_group()
 
 
-def _run(world, log_n, log_b, min_chunk_log):
+def _run(world, log_n, log_b, min_chunk_log, min_layer_log=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, min_chunk_log, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, min_chunk_log, q, min_layer_log)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=300) for _ in range(world)]
@@ -67,6 +67,19 @@ def test_sharded_prover_matches_oracle(orc, world, log_n, log_b, min_chunk_log):
         assert data == want.proof and state == want.state, f"rank {rank}: proof differs from the oracle"
         assert calls["lde"] == 1 and calls["compose"] == 1 and calls["fold"] == log_n
     assert orc.verify(res[0][1], log_n, log_b, want.public_last) == 0
+
+
+@pytest.mark.parametrize("world,log_n,log_b,min_chunk_log,min_layer_log,want_sharded", [
+    (2, 7, 2, 2, 7, 3),        # layers of 2^9, 2^8, 2^7 values sharded, the rest replicated
+    (2, 7, 2, 2, 30, 1),       # total-size threshold above the domain: only f and cp are sharded
+    (4, 6, 3, 1, 8, 2)])
+def test_sharded_layer_size_threshold(orc, world, log_n, log_b, min_chunk_log, min_layer_log, want_sharded):
+    """Where the proof switches from sharded to replicated layers is a cost decision only: same bytes."""
+    want = orc.prove(log_n, log_b)
+    res = _run(world, log_n, log_b, min_chunk_log, min_layer_log)
+    for rank, data, state, n_sharded, calls, roots in res:
+        assert n_sharded == want_sharded
+        assert data == want.proof and state == want.state, f"rank {rank}"
 
 
 def test_sharded_requires_world_dividing_blowup(zk):

@@ -13,9 +13,11 @@ shift w h^r.  The only exchange step is the commitment: Merkle leaves are in nat
 per committed layer ONE all-to-all of the 4-byte values turns the cyclic layout into contiguous
 blocks of m/G leaves, each rank hashes its subtree, the G subtree roots (32 B each) are
 all-gathered and the top log2(G) levels are hashed on the host by every rank.  Once a layer has
-fewer than 2^min_chunk_log leaves per (rank, peer) chunk (default 2^14: below that the two
-collectives of a commitment cost more than hashing the whole layer redundantly) it is
-all-gathered once and the remaining small layers are folded and committed on every rank.  The transcript
+fewer than 2^min_layer_log values in total (default 2^22: a sharded commitment carries ~250 us of
+fixed cost -- two collectives, two device-to-host reads, the latency phase of the subtree -- which
+is what hashing 2^21 leaves redundantly costs) or fewer than 2^min_chunk_log leaves per (rank, peer)
+chunk, it is all-gathered once and the remaining layers are folded and committed on every rank in
+one C call (zk_tail_*).  The transcript
 (channel.rs) runs identically on every rank, so challenges are never broadcast.  No all-reduce.
 
 Collectives per proof: (number of sharded layers + 1) all-to-alls, as many 256-byte
@@ -221,7 +223,11 @@ class HipBackend:
 class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
 
-    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=14, overlap_min_log=22):
+    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=None, overlap_min_log=22, min_layer_log=None):
+        if min_layer_log is None:                      # an explicit chunk threshold alone decides (tests shard tiny domains)
+            min_layer_log = 22 if min_chunk_log is None else 0
+        if min_chunk_log is None:
+            min_chunk_log = 14
         self.log_n, self.log_b, self.comm, self.be = log_n, log_blowup, comm, backend
         G = comm.world
         self.G, self.rank = G, comm.rank
@@ -231,10 +237,12 @@ class ShardedProver:
         self.L = log_n + log_blowup
         self.R = log_n
         self.n, self.N, self.B = 1 << log_n, 1 << self.L, 1 << log_blowup
-        # FRI layer rho (2^(L-rho) values) stays sharded while a (rank, peer) chunk has >= 2^min_chunk_log leaves
-        self.n_sharded = sum(1 for rho in range(self.R + 1) if self.L - rho - 2 * self.lg >= min_chunk_log)
-        if self.n_sharded < 1:
+        # FRI layer rho (2^(L-rho) values) stays sharded while it has >= 2^min_layer_log values and a
+        # (rank, peer) chunk has >= 2^min_chunk_log leaves; layer 0 (cp) is always sharded, like f
+        if self.L - 2 * self.lg < min_chunk_log:
             raise ZkError(-1, "domain too small to shard: use the single-GPU prover")
+        self.n_sharded = max(1, sum(1 for rho in range(self.R + 1)
+                                    if self.L - rho >= min_layer_log and self.L - rho - 2 * self.lg >= min_chunk_log))
         h = root_of_unity(self.L)
         self.shift = GEN_W * _pow(h, self.rank) % P
         be = self.be
