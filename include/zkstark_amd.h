@@ -267,6 +267,16 @@ int zk_dev_merkle_build_ex(const uint32_t *d_vals, uint32_t log_m, uint32_t *d_n
  * u*parts + q = d_recv[q*cnt + u] (zk_dev_interleave fused into the leaf hashing). */
 int zk_dev_merkle_build_interleaved(const uint32_t *d_recv, uint32_t log_parts, uint32_t log_cnt,
                                     uint32_t *d_nodes, void *stream, int hash_kind);
+/* Commitment with the root handed to the host (what prover.rs:85 feeds the channel): the tree of
+ * zk_dev_merkle_build_ex (log_parts = 0, d_src in natural order) or zk_dev_merkle_build_interleaved
+ * (log_parts > 0).  With SHA-256 and SHA extensions on the CPU the device stops at depth 8, the calling
+ * thread hashes the 255 nodes above (see zk_ctx_set_host_levels) and a copy ordered on `stream` completes
+ * d_nodes; the call returns once the root is known.  One committer per host thread. */
+typedef struct zk_committer zk_committer;
+int zk_committer_create(int device, zk_committer **out);
+int zk_committer_destroy(zk_committer *k);
+int zk_dev_merkle_commit(zk_committer *k, const uint32_t *d_src, uint32_t log_parts, uint32_t log_cnt,
+                         uint32_t *d_nodes, void *stream, int hash_kind, uint8_t root_out[32]);
 /* The same tree in 2^c aligned chunks, so that hashing chunk i overlaps the exchange of chunk i+1: chunk
  * `chunk` covers leaves [chunk << s, (chunk+1) << s), s = log_parts + log_cnt, arriving in its own
  * receive buffer in all-to-all order; the throughput-bound levels are built in place in the heap over

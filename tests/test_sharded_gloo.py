@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, log_n, log_b, min_chunk_log, q, min_layer_log=None):
+def _worker(rank, world, port, log_n, log_b, min_chunk_log, q, min_layer_log=None, use_board=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,19 +34,25 @@ def _worker(rank, world, port, log_n, log_b, min_chunk_log, q, min_layer_log=Non
         from sharded_testlib import OracleBackend
         from zkstark_amd import sharded
         be = OracleBackend()
-        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(), be, min_chunk_log=min_chunk_log, min_layer_log=min_layer_log)
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(), be, min_chunk_log=min_chunk_log, min_layer_log=min_layer_log,
+                                   use_board=use_board)
         sp.trace_upload(oracle.trace_fibsq((1 << log_n) - 1))
         proof = sp.prove()
-        q.put((rank, proof.data, proof.state, sp.n_sharded, dict(be.calls), [r.hex() for r in sp.transcript["roots"]]))
+        proof2 = sp.prove()                          # a second proof on the same prover: exchange numbers keep running
+        assert proof2.data == proof.data
+        calls = dict(be.calls)
+        calls["board_exchanges"] = sp.n_exchanges if sp.board is not None else -1
+        q.put((rank, proof.data, proof.state, sp.n_sharded, calls, [r.hex() for r in sp.transcript["roots"]]))
+        sp.close()
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, log_n, log_b, min_chunk_log, min_layer_log=None):
+def _run(world, log_n, log_b, min_chunk_log, min_layer_log=None, use_board=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, min_chunk_log, q, min_layer_log)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, min_chunk_log, q, min_layer_log, use_board)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=300) for _ in range(world)]
@@ -65,8 +71,17 @@ def test_sharded_prover_matches_oracle(orc, world, log_n, log_b, min_chunk_log):
         assert n_sharded >= 2, "the test must exercise sharded FRI layers"
         assert roots == [bytes(r).hex() for r in want.roots], f"rank {rank}: roots differ"
         assert data == want.proof and state == want.state, f"rank {rank}: proof differs from the oracle"
-        assert calls["lde"] == 1 and calls["compose"] == 1 and calls["fold"] == log_n
+        assert calls["lde"] == 2 and calls["compose"] == 2 and calls["fold"] == 2 * log_n          # two proofs
+        assert calls["board_exchanges"] == 2 * (n_sharded + 1), "subtree roots must travel through the shared-memory board"
     assert orc.verify(res[0][1], log_n, log_b, want.public_last) == 0
+
+
+def test_sharded_without_root_board(orc):
+    """The collective fallback (ranks on different nodes): all-gather of the subtree roots, same proof."""
+    want = orc.prove(6, 3)
+    for rank, data, state, n_sharded, calls, roots in _run(2, 6, 3, 2, use_board=False):
+        assert calls["board_exchanges"] == -1
+        assert data == want.proof and state == want.state
 
 
 @pytest.mark.parametrize("world,log_n,log_b,min_chunk_log,min_layer_log,want_sharded", [

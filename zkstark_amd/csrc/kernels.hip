@@ -722,9 +722,9 @@ hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* n
 }
 // commitment of a block whose leaves are still in all-to-all order (no interleave pass, no block buffer)
 hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, hipStream_t s,
-                                           Profiler* prof, int hash) {
+                                           Profiler* prof, int hash, const MailArgs& mail) {
     uint32_t log_m = log_parts + log_cnt;
-    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, MailArgs{}, hash);
+    return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, mail, hash);
 }
 // One chunk (1 / 2^log_chunks of the leaves, still in all-to-all order in its own receive buffer) of a
 // tree over 2^log_m leaves: levels up to the chunk root.  launch_merkle_finish joins the chunk roots.

@@ -155,7 +155,7 @@ hipError_t launch_scatter(const uint32_t* stage, const ScatterSeg* segs, uint32_
                           hipStream_t s, Profiler* prof = nullptr);
 
 hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, hipStream_t s,
-                                           Profiler* prof = nullptr, int hash = 0);
+                                           Profiler* prof = nullptr, int hash = 0, const MailArgs& mail = MailArgs{});
 hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, uint32_t log_m,
                                      uint32_t chunk, hipStream_t s, Profiler* prof = nullptr, int hash = 0);
 hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof = nullptr, int hash = 0);

@@ -428,14 +428,12 @@ int do_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
 
 // Waits until the mailbox carries the sequence number of the last commit launch (polling host-coherent
 // memory: no blit kernel, no stream synchronisation on the commit -> challenge path).
-int wait_mail(zk_ctx* c) {
-    const uint32_t want = c->mail_seq;
-    const uint32_t* flag = c->h_mailbox;
+int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream) {
     auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
         if ((++spins & 0xFFFF) == 0) {
-            if (hipStreamQuery(c->stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
+            if (hipStreamQuery(stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
                 return fail(ZK_ERR_HIP, "merkle digests were never posted (stream drained)");
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
                 return fail(ZK_ERR_HIP, "timed out waiting for merkle digests");
@@ -443,6 +441,7 @@ int wait_mail(zk_ctx* c) {
     }
     return ZK_OK;
 }
+int wait_mail(zk_ctx* c) { return wait_flag(c->h_mailbox, c->mail_seq, c->stream); }
 
 // Root posted by a whole-tree build.
 int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
@@ -1223,6 +1222,79 @@ int zk_dev_merkle_build_interleaved(const uint32_t* d_recv, uint32_t log_parts, 
     HIPCHK(launch_merkle_build_interleaved(d_recv, log_parts, log_cnt, d_nodes, (hipStream_t)stream, dev_prof(), hash_kind));
     return ZK_OK;
 }
+// ---- committer: zk_dev_merkle_build* + root on the host, with the tree top finished by the calling thread ----
+struct zk_committer {
+    int device = 0;
+    uint32_t* h_mail = nullptr;     // pinned, mapped: MailArgs layout
+    uint32_t* d_mail = nullptr;
+    uint32_t* d_counter = nullptr;
+    uint32_t* h_stage = nullptr;    // pinned, mapped: host-built top nodes, then one ScatterSeg
+    uint32_t* d_stage = nullptr;
+    uint32_t seq = 0, top = 0;
+};
+int zk_committer_destroy(zk_committer* k) {
+    if (!k) return ZK_OK;
+    (void)hipSetDevice(k->device);
+    (void)hipDeviceSynchronize();                      // a scatter launch may still read the staging buffer
+    if (k->h_mail) (void)hipHostFree(k->h_mail);
+    if (k->h_stage) (void)hipHostFree(k->h_stage);
+    if (k->d_counter) (void)hipFree(k->d_counter);
+    delete k;
+    return ZK_OK;
+}
+int zk_committer_create(int device, zk_committer** out) {
+    if (!out) return fail(ZK_ERR_INVALID, "zk_committer_create: out is null");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    zk_committer* k = new (std::nothrow) zk_committer();
+    if (!k) return fail(ZK_ERR_NOMEM, "out of host memory");
+    k->device = device;
+    const size_t stage_bytes = ((size_t)16 << kMaxHostLog) * 4 + sizeof(ScatterSeg);
+    hipError_t e = hipHostMalloc((void**)&k->h_mail, kMailValsOff * 4, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&k->d_mail, k->h_mail, 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&k->h_stage, stage_bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&k->d_stage, k->h_stage, 0);
+    if (e == hipSuccess) e = hipMalloc((void**)&k->d_counter, 64);
+    if (e == hipSuccess) e = hipMemset(k->d_counter, 0, 64);
+    if (e != hipSuccess) { zk_committer_destroy(k); return fail(ZK_ERR_HIP, "zk_committer_create: %s", hipGetErrorString(e)); }
+    memset(k->h_mail, 0, kMailValsOff * 4);
+    k->top = host_sha_available() ? 8 : 0;
+    if (const char* v = getenv("ZK_HOST_TOP_LOG")) k->top = (uint32_t)atoi(v) <= kMaxHostLog ? (uint32_t)atoi(v) : k->top;
+    *out = k;
+    return ZK_OK;
+}
+// Tree over 2^(log_parts + log_cnt) leaves (log_parts = 0: d_src in natural order; else in all-to-all order as
+// for zk_dev_merkle_build_interleaved), root returned to the host.  The device stops at depth `top`, the calling
+// thread hashes the levels above and a stream-ordered copy completes d_nodes (merkle.rs:14-51 either way).
+int zk_dev_merkle_commit(zk_committer* k, const uint32_t* d_src, uint32_t log_parts, uint32_t log_cnt, uint32_t* d_nodes, void* stream,
+                         int hash_kind, uint8_t root_out[32]) {
+    if (!k || !d_src || !d_nodes || !root_out || log_parts + log_cnt > 30 || (hash_kind != 0 && hash_kind != 1))
+        return fail(ZK_ERR_INVALID, "zk_dev_merkle_commit: bad argument");
+    HIPCHK(hipSetDevice(k->device));
+    const uint32_t log_m = log_parts + log_cnt;
+    hipStream_t s = (hipStream_t)stream;
+    MailArgs m;
+    m.mailbox = k->d_mail;
+    m.seq = ++k->seq;
+    m.counter = k->d_counter;
+    m.top = (hash_kind == 0 && k->top && log_m > k->top) ? k->top : 0;
+    if (log_parts) HIPCHK(launch_merkle_build_interleaved(d_src, log_parts, log_cnt, d_nodes, s, dev_prof(), hash_kind, m));
+    else HIPCHK(launch_merkle_build(d_src, log_m, d_nodes, s, dev_prof(), m, hash_kind));
+    int rc = wait_flag(k->h_mail, m.seq, s);
+    if (rc) return rc;
+    if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
+    const size_t cnt = (size_t)1 << m.top;
+    uint32_t* nodes = k->h_stage;
+    memcpy(nodes + 8 * (cnt - 1), k->h_mail + kMailDigests, cnt * 32);
+    host_sha_reduce(nodes, m.top);
+    digest_words_to_bytes(nodes, root_out);
+    ScatterSeg* seg = reinterpret_cast<ScatterSeg*>(k->h_stage + ((size_t)16 << kMaxHostLog));
+    *seg = ScatterSeg{0, 0, (uint32_t)((cnt - 1) * 8), 0};
+    HIPCHK(launch_scatter(k->d_stage, reinterpret_cast<ScatterSeg*>(k->d_stage + ((size_t)16 << kMaxHostLog)), 1, (double)seg->words,
+                          d_nodes, nullptr, s, dev_prof()));
+    return ZK_OK;
+}
+
 int zk_dev_merkle_build_chunk(const uint32_t* d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* d_nodes, uint32_t log_m,
                               uint32_t chunk, void* stream, int hash_kind) {
     if (!d_recv || !d_nodes || log_m > 30 || log_parts + log_cnt > log_m || (hash_kind != 0 && hash_kind != 1) ||

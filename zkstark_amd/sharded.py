@@ -117,6 +117,92 @@ class Comm:
         return out
 
 
+    def agree(self, ok):
+        """True iff `ok` holds on every rank (one tiny all-reduce on the backend's own kind of tensor)."""
+        import torch
+        on_gpu = self.dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class RootBoard:
+    """Exchange of the G subtree roots of a commitment between the ranks of ONE node through shared memory.
+
+    A commitment ends with every rank needing all G roots (32 bytes each) on the host to hash the top of
+    the tree and feed the channel (prover.rs:85).  As a device collective that is an all-gather plus a
+    device-to-host read, ~100 us of fixed cost for 256 bytes; through a page in /dev/shm it is a store
+    and G polled loads.  Slot = [digest 8 words | sequence number]; x86 keeps the two stores and the two
+    loads in order.  Built only when every rank can map the file (same node); otherwise the caller keeps
+    using the collective."""
+    RING = 4                                   # a commit cannot run more than one exchange ahead of the slowest rank
+
+    def __init__(self, comm, tag):
+        import mmap
+        import os
+        self.G, self.rank = comm.world, comm.rank
+        self.path = "/dev/shm/zkstark_amd_%s_%s_%s" % (os.environ.get("MASTER_ADDR", "local").replace("/", "_"),
+                                                        os.environ.get("MASTER_PORT", "0"), tag)
+        size = self.RING * self.G * 64
+        self.mm = None
+        ok = True
+        if self.rank == 0:
+            try:
+                if os.path.exists(self.path):
+                    os.unlink(self.path)
+                fd = os.open(self.path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                os.ftruncate(fd, size)
+                self.mm = mmap.mmap(fd, size)
+                os.close(fd)
+            except OSError:
+                ok = False
+        comm.barrier()                           # the file exists (or rank 0 failed) before anybody opens it
+        if self.rank != 0:
+            try:
+                fd = os.open(self.path, os.O_RDWR)
+                ok = os.fstat(fd).st_size == size
+                if ok:
+                    self.mm = mmap.mmap(fd, size)
+                os.close(fd)
+            except OSError:
+                ok = False
+        self.ok = comm.agree(ok)                 # also orders "everybody has mapped it" before the unlink
+        if self.rank == 0 and os.path.exists(self.path):
+            os.unlink(self.path)                 # the mapping keeps the memory alive; no file is left behind
+        if not self.ok:
+            self.close()
+            return
+        self.slots = np.ndarray((self.RING, self.G, 16), dtype=np.uint32, buffer=self.mm)
+
+    def close(self):
+        self.slots = None
+        if self.mm is not None:
+            try:
+                self.mm.close()
+            except BufferError:
+                pass
+            self.mm = None
+
+    def exchange(self, seq, mine, timeout=120.0):
+        """mine: this rank's 32-byte digest for exchange number seq (1, 2, ...): returns the G digests."""
+        row = self.slots[seq % self.RING]
+        row[self.rank, :8] = np.frombuffer(mine, dtype=np.uint32)
+        row[self.rank, 8] = seq                  # after the digest (program order = store order on x86)
+        out = []
+        t0 = None
+        for q in range(self.G):
+            while int(row[q, 8]) != seq:
+                if t0 is None:
+                    t0 = time.perf_counter()
+                elif time.perf_counter() - t0 > timeout:
+                    raise ZkError(-6, f"rank {q} did not post its subtree root (exchange {seq})")
+            out.append(row[q, :8].tobytes())
+        return out
+
+
 class LocalComm:
     """world = 1 (no process group): lets the sharded code path run in a single process."""
     rank, world, force = 0, 1, False
@@ -148,6 +234,9 @@ class HipBackend:
             self.lib.zk_dom_destroy(h)
         for h in getattr(self, "_tails", []):
             self.lib.zk_ctx_destroy(h)
+        if getattr(self, "_committer", None) is not None:
+            self.lib.zk_committer_destroy(self._committer)
+            self._committer = None
         self._doms, self._tails = [], []
 
     def empty(self, nwords):
@@ -177,6 +266,16 @@ class HipBackend:
 
     def merkle_finish(self, nodes, log_m, log_chunks):
         check(self.lib.zk_dev_merkle_finish(nodes.data_ptr(), log_m, log_chunks, self._stream(), 0))
+
+    def commit(self, src, log_parts, log_cnt, nodes):
+        """Tree over 2^(log_parts+log_cnt) leaves (log_parts > 0: still in all-to-all order) with the root
+        returned as bytes: the device stops at depth 8, this thread hashes the top (zk_dev_merkle_commit)."""
+        if getattr(self, "_committer", None) is None:
+            self._committer = C.c_void_p()
+            check(self.lib.zk_committer_create(self.index, C.byref(self._committer)))
+        root = C.create_string_buffer(32)
+        check(self.lib.zk_dev_merkle_commit(self._committer, src.data_ptr(), log_parts, log_cnt, nodes.data_ptr(), self._stream(), 0, root))
+        return root.raw
 
     def merkle_interleaved(self, recv, log_parts, log_cnt, nodes):
         """Tree over leaves still in all-to-all order (interleave fused into the leaf hashing)."""
@@ -223,7 +322,7 @@ class HipBackend:
 class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
 
-    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=None, overlap_min_log=22, min_layer_log=None):
+    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=None, overlap_min_log=22, min_layer_log=None, use_board=True):
         if min_layer_log is None:                      # an explicit chunk threshold alone decides (tests shard tiny domains)
             min_layer_log = 22 if min_chunk_log is None else 0
         if min_chunk_log is None:
@@ -275,6 +374,14 @@ class ShardedProver:
         # the first replicated layer arrives as G cyclic pieces before it is interleaved
         self.gbuf = be.empty(max(1, self.N >> self.n_sharded)) if self.n_sharded <= self.R else None
         self.have_trace = False
+        # subtree roots travel through shared memory when all ranks sit on one node (RootBoard)
+        self.board, self.n_exchanges = None, 0
+        if (G > 1 or comm.force) and use_board and hasattr(comm, "agree"):
+            ShardedProver._instances += 1
+            board = RootBoard(comm, ShardedProver._instances)
+            self.board = board if board.ok else None
+
+    _instances = 0
 
     # layer ids: 0 = f, 1 + rho = FRI layer rho
     def _sharded(self, rho):
@@ -327,21 +434,34 @@ class ShardedProver:
                     works[c].wait()
                 be.merkle_chunk(recv[c * G * cc:(c + 1) * G * cc], lg, log_cnt - lk, nodes, m_log - lg, c)
             be.merkle_finish(nodes, m_log - lg, lk)
+            mine = None
         elif G > 1 or self.comm.force:
             self.comm.all_to_all(loc, recv)                       # chunk q: rank q's j in my block
-            if hasattr(be, "merkle_interleaved"):                 # leaf u*G + q = recv[q][u], hashed in place
+            mine = None
+            if hasattr(be, "commit"):                             # leaf u*G + q = recv[q][u], hashed in place; root on the host
+                mine = be.commit(recv, lg, m_log - 2 * lg, nodes)
+            elif hasattr(be, "merkle_interleaved"):
                 be.merkle_interleaved(recv, lg, m_log - 2 * lg, nodes)
             else:
                 be.interleave(recv, block, lg, m_log - 2 * lg)    # block[u*G + q] = recv[q][u]
                 be.merkle(block, m_log - lg, nodes)
+        elif hasattr(be, "commit"):
+            mine = be.commit(loc, 0, m_log, nodes)
         else:
             be.merkle(loc, m_log - lg, nodes)
+            mine = None
         if G > 1 or self.comm.force:
-            self.comm.all_gather(nodes[:8], self.subroot_all)
-            words = be.to_host(self.subroot_all).reshape(G, 8)
+            if self.board is not None:
+                if mine is None:
+                    mine = words_to_bytes(be.to_host(nodes[:8]))
+                self.n_exchanges += 1
+                subroots = self.board.exchange(self.n_exchanges, mine)
+            else:
+                self.comm.all_gather(nodes[:8], self.subroot_all)
+                subroots = [words_to_bytes(w) for w in be.to_host(self.subroot_all).reshape(G, 8)]
         else:
-            words = be.to_host(nodes[:8]).reshape(1, 8)
-        top = host_merkle_top([words_to_bytes(w) for w in words])
+            subroots = [mine if mine is not None else words_to_bytes(be.to_host(nodes[:8]))]
+        top = host_merkle_top(subroots)
         self.tops[lid] = top
         return top[0]
 
@@ -496,6 +616,9 @@ class ShardedProver:
                 check(lib.zk_channel_commit(h, b, len(b)))
 
     def close(self):
+        if self.board is not None:
+            self.board.close()
+            self.board = None
         self.be.close()
 
 
