@@ -328,6 +328,7 @@ struct zk_ctx {
     std::vector<uint32_t> tail_vals;    // current host-side FRI layer (valid when tail_log != 0)
     uint32_t tail_log = 0;              // log2 size of tail_vals
     bool tail_have = false;             // false: the current FRI layer lives on the device only
+    double t_wait = 0, t_host_hash = 0, t_launch = 0;   // ZK_HOST_TIMING: where the host thread spends a proof
     bool tail = false;                  // FRI-tail context (zk_tail_*): no trace / LDE / composition
     uint32_t queries = 1;               // decommitment queries (1 = the reference, prover.rs:263)
     int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
@@ -441,7 +442,13 @@ int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream) {
     }
     return ZK_OK;
 }
-int wait_mail(zk_ctx* c) { return wait_flag(c->h_mailbox, c->mail_seq, c->stream); }
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int wait_mail(zk_ctx* c) {
+    double t0 = now_us();
+    int rc = wait_flag(c->h_mailbox, c->mail_seq, c->stream);
+    c->t_wait += now_us() - t0;
+    return rc;
+}
 
 // Root posted by a whole-tree build.
 int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
@@ -475,9 +482,11 @@ int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
     if (!nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
     int rc = wait_mail(c);
     if (rc) return rc;
+    double t0 = now_us();
     memcpy(nodes + 8 * (cnt - 1), c->h_mailbox + kMailDigests, cnt * 32);
     host_sha_reduce(nodes, H);
     digest_words_to_bytes(nodes, root);
+    c->t_host_hash += now_us() - t0;
     if (c->tail_have && c->tail_log == layer_log(c, tree) && tree >= 1) {     // this launch dumped its leaves (mail_of)
         c->tail_vals.assign(c->h_mailbox + kMailValsOff, c->h_mailbox + kMailValsOff + ((size_t)1 << c->tail_log));
     }
@@ -489,6 +498,7 @@ int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
 int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[32]) {
     const uint32_t log_out = c->L - round - 1;
     const size_t half = (size_t)1 << log_out;
+    const double t_begin = now_us();
     uint32_t* vals = stage_alloc(c, half);
     uint32_t* nodes = stage_alloc(c, (2 * half - 1) * 8);
     if (!vals || !nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
@@ -508,6 +518,7 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     digest_words_to_bytes(nodes, root);
     c->tail_vals.assign(vals, vals + half);
     c->tail_log = log_out;
+    c->t_host_hash += now_us() - t_begin;
     int rc = stage_seg(c, vals, c->layer_off[2 + round], half, 1);
     if (!rc) rc = stage_seg(c, nodes, c->tree_off[2 + round], (2 * half - 1) * 8, 0);
     return rc;
@@ -519,7 +530,10 @@ int fri_round_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     int rc = do_fold_commit(c, round, beta_raw);
     return rc ? rc : read_commit(c, 2 + round, root);
 }
-void begin_proof(zk_ctx* c) { c->stage_used = 0; c->n_segs = 0; c->seg_words = 0; c->tail_log = 0; c->tail_have = false; }
+void begin_proof(zk_ctx* c) {
+    c->stage_used = 0; c->n_segs = 0; c->seg_words = 0; c->tail_log = 0; c->tail_have = false;
+    c->t_wait = c->t_host_hash = c->t_launch = 0;
+}
 // Device copies of everything the host built, stream-ordered before any later read of trees / layers.
 int flush_host_parts(zk_ctx* c) {
     HIPCHK(launch_scatter(c->d_stage, c->d_segs, c->n_segs, c->seg_words, c->d_trees, c->d_layers, c->stream, prof_of(c)));
@@ -597,6 +611,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
         memcpy(c->info.roots[2 + r], root, 32);
     }
     lap("lde .. last root");
+    if (timing) fprintf(stderr, "[zk timing]   of which: waiting for the device %.1f us, host hashing (tops + tail) %.1f us\n", c->t_wait, c->t_host_hash);
     // last layer: B evaluations of a degree-0 polynomial (prover.rs:238, :251); free term prover.rs:254
     uint32_t free_term = 0;
     if ((rc = last_layer_value(c, &free_term))) return rc;
