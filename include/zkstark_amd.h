@@ -168,6 +168,27 @@ int zk_ctx_set_profiling(zk_ctx *ctx, uint32_t class_mask);
 /* Copies the accumulated statistics (count <= ZK_K_COUNT entries); reset != 0 clears them. */
 int zk_kernel_stats(zk_ctx *ctx, zk_kernel_stat *out, size_t count, int reset);
 
+/* ---- batched proving ---------------------------------
+ * 2^log_batch independent proofs of one size (prover.rs:9-293 each, its own Channel each) computed in
+ * lockstep: the layers of the batch are stored proof-major, so every stage is ONE launch of the kernels
+ * a single proof uses on a domain batch times larger, and the trees of the batch are the bottom of one
+ * heap whose nodes of depth log_batch are the per-proof roots.  Every proof is byte-identical to what
+ * zk_prove returns for the same trace.  log_batch <= 10, log_blowup >= 1. */
+typedef struct zk_batch zk_batch;
+int zk_batch_create(int device, uint32_t log_n, uint32_t log_blowup, uint32_t log_batch, zk_batch **out);
+int zk_batch_destroy(zk_batch *b);
+size_t zk_batch_size(const zk_batch *b);                    /* 2^log_batch */
+size_t zk_batch_device_bytes(const zk_batch *b);
+/* traces: [batch][n-1] canonical residues (prover.rs:32-39 per proof), uploaded and kept resident. */
+int zk_batch_set_traces(zk_batch *b, const uint32_t *traces);
+/* The same traces generated on the device from seeds a0[p], a1[p] (one lane per trace). */
+int zk_batch_gen_fibsq(zk_batch *b, const uint32_t *a0, const uint32_t *a1);
+/* out[p] = a[n-2] of proof p: the public input its verifier needs (prover.rs:42, proof.rs:68). */
+int zk_batch_public_last(const zk_batch *b, uint32_t *out);
+/* proofs_out: [batch][stride] bytes, stride >= zk_proof_data_len(log_n, log_blowup); states_out:
+ * [batch][32].  Fails with ZK_ERR_CHECK, naming the proof, if a trace breaks the constraints. */
+int zk_batch_prove(zk_batch *b, uint8_t *proofs_out, size_t stride, uint8_t *states_out);
+
 /* ---- proof: proof.rs ------------------------------------------------------- */
 /* Proof::verify (proof.rs:15-149), CPU only, generalised from the literals
  * (1024, 8192, 10, 2338775057) to (log_n, log_blowup, public_last). */

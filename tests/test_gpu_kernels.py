@@ -424,3 +424,58 @@ def test_host_levels_argument_checks(zk):
         q = ctx.prove(zk.trace_fibsq(1023))
     assert p.data == q.data
     p.verify(strict=True)
+
+
+# ---- batched proving ----------------------------------------------------------
+@pytest.mark.parametrize("log_n,log_b,log_batch", [(10, 3, 0), (10, 3, 1), (10, 3, 3), (6, 2, 4), (4, 1, 2), (2, 1, 3), (12, 3, 2),
+                                                   (7, 4, 5), (5, 5, 1), (14, 2, 1), (9, 3, 6)])
+def test_batch_prover_matches_oracle(zk, orc, log_n, log_b, log_batch):
+    """Every proof of a batch equals the oracle's proof for its own trace (its own transcript and
+    challenges); traces generated on the device from per-proof seeds (prover.rs:32-39)."""
+    batch = 1 << log_batch
+    a0s = [1] * batch                                        # prover.rs:105: the first constraint pins a[0] = 1
+    a1s = [3141592 + 977 * p for p in range(batch)]
+    with zk.BatchContext(log_n, log_b, log_batch) as bc:
+        bc.gen_fibsq(a0s, a1s)
+        proofs = bc.prove()
+        again = bc.prove()                                   # resident traces, buffers reusable
+    check = sorted({0, min(1, batch - 1), batch // 2, batch - 1})
+    for p in range(batch):
+        assert proofs[p].data == again[p].data
+    for p in check:
+        want = orc.prove(log_n, log_b, a0s[p], a1s[p], want_vectors=False)
+        assert want.rc == 0
+        assert proofs[p].data == want.proof and proofs[p].state == want.state, f"proof {p}"
+        assert proofs[p].public_last == want.public_last
+        proofs[p].verify(strict=True)
+    for p in range(batch):
+        proofs[p].verify()
+
+
+def test_batch_prover_host_traces_and_single_context(zk):
+    """Traces handed over from the host; each proof equals Context.prove() of the same trace."""
+    log_n, log_b, log_batch = 8, 3, 3
+    traces = np.stack([zk.trace_fibsq((1 << log_n) - 1, 1, 5 + p) for p in range(1 << log_batch)])
+    with zk.BatchContext(log_n, log_b, log_batch) as bc:
+        bc.set_traces(traces)
+        proofs = bc.prove()
+        assert list(bc.public_last()) == [int(t[-1]) for t in traces]
+    with zk.Context(log_n, log_b) as ctx:
+        for p in (0, 3, 7):
+            one = ctx.prove(traces[p])
+            assert one.data == proofs[p].data and one.state == proofs[p].state
+
+
+def test_batch_prover_rejects_a_bad_trace(zk):
+    traces = np.stack([zk.trace_fibsq(255, 1, 9 + p) for p in range(4)])
+    traces[2, 100] = (int(traces[2, 100]) + 1) % P
+    with zk.BatchContext(8, 2, 2) as bc:
+        bc.set_traces(traces)
+        with pytest.raises(zk.ZkError, match="proof 2"):
+            bc.prove()
+        with pytest.raises(zk.ZkError):
+            bc.set_traces(traces[:3])
+    with pytest.raises(zk.ZkError):
+        zk.BatchContext(10, 3, 11)
+    with pytest.raises(zk.ZkError):
+        zk.BatchContext(10, 0, 2)

@@ -11,5 +11,5 @@ Host-side mirror of the reference crate's interface for this path
 All device work goes through libzkstark_amd.so; there is no CPU fallback.
 """
 from ._lib import ZkError, load  # noqa: F401
-from .host import (P, Channel, Context, Merkle, Proof, compute_root_from_path, field, generate_proof,  # noqa: F401
+from .host import (P, BatchContext, Channel, Context, Merkle, Proof, compute_root_from_path, field, generate_proof,  # noqa: F401
                    lde, ntt, trace_fibsq, trace_fibsq_batch)

@@ -86,6 +86,14 @@ SYMBOLS = {
     "zk_dev_merkle_build_ex": (_int, [_vp, _u32, _vp, _vp, _int]),
     "zk_dev_merkle_build_interleaved": (_int, [_vp, _u32, _u32, _vp, _vp, _int]),
     "zk_dev_merkle_build_chunk": (_int, [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _int]),
+    "zk_batch_create": (_int, [_int, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "zk_batch_destroy": (_int, [_vp]),
+    "zk_batch_size": (_sz, [_vp]),
+    "zk_batch_device_bytes": (_sz, [_vp]),
+    "zk_batch_set_traces": (_int, [_vp, _vp]),
+    "zk_batch_gen_fibsq": (_int, [_vp, _vp, _vp]),
+    "zk_batch_public_last": (_int, [_vp, _vp]),
+    "zk_batch_prove": (_int, [_vp, _vp, _sz, _vp]),
     "zk_committer_create": (_int, [_int, C.POINTER(_vp)]),
     "zk_committer_destroy": (_int, [_vp]),
     "zk_dev_merkle_commit": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _int, _vp]),

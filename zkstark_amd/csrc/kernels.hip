@@ -72,6 +72,8 @@ __device__ __forceinline__ void tile_coords(uint32_t l, uint32_t logR, uint32_t 
 template <uint32_t MODE>
 __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(NttPassArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    p.src += (size_t)blockIdx.y * p.src_stride;      // batch of independent transforms
+    p.dst += (size_t)blockIdx.y * p.dst_stride;
     const uint32_t logR = p.logR, logS = p.logS, logC = p.logC;
     const uint32_t R = 1u << logR, C = 1u << logC, pitch = C + 1u;
     uint32_t* tile = smem;              // R * pitch words
@@ -171,16 +173,17 @@ hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Pr
     // algorithmic bytes: every element read once and written once (the LDE pass reads n, writes N)
     double bytes = mode == NTT_DIT_LDE ? 4.0 * ((double)((size_t)1 << (a.log_total - a.logS)) + (double)((size_t)1 << a.log_total))
                                        : 8.0 * (double)((size_t)1 << a.log_total);
-    ScopedKernelTimer tm(prof, K_NTT, bytes, s);
+    const uint32_t batch = a.batch ? a.batch : 1;
+    ScopedKernelTimer tm(prof, K_NTT, bytes * batch, s);
     hipError_t ferr = hipSuccess;
     if (launch_ntt_pass_fast(a, mode, s, &ferr)) return ferr;
     uint32_t cols_log = a.log_total - a.logR;
     uint32_t blocks = 1u << (cols_log - a.logC);
     size_t shmem = ((size_t)(1u << a.logR) * ((1u << a.logC) + 1u) + (1u << a.logR) / 2u) * sizeof(uint32_t);
     switch (mode) {
-        case NTT_DIF: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIF>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
-        case NTT_DIT: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
-        case NTT_DIT_LDE: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT_LDE>, dim3(blocks), dim3(kNttThreads), shmem, s, a); break;
+        case NTT_DIF: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIF>, dim3(blocks, batch), dim3(kNttThreads), shmem, s, a); break;
+        case NTT_DIT: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT>, dim3(blocks, batch), dim3(kNttThreads), shmem, s, a); break;
+        case NTT_DIT_LDE: hipLaunchKernelGGL(ntt_pass_kernel<NTT_DIT_LDE>, dim3(blocks, batch), dim3(kNttThreads), shmem, s, a); break;
     }
     return hipGetLastError();
 }
@@ -189,9 +192,11 @@ hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Pr
 //   out[pos] = (U[pos] - U[n-1] g^(k+1)) * shift^k / n,   k = true index of storage position pos.
 // The first term removes the degree-(n-1) coefficient (the reference interpolates n-1 points,
 // prover.rs:60: "virtual last trace point"), shift^k moves to the coset (prover.rs:69).
-__global__ __launch_bounds__(256) void coef_prepare_kernel(const uint32_t* U, uint32_t* out, CoefPrepArgs a) {
+__global__ __launch_bounds__(256) void coef_prepare_kernel(const uint32_t* U, uint32_t* out, CoefPrepArgs a, size_t u_stride, size_t out_stride) {
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
     if (pos >= n) return;
+    U += (size_t)blockIdx.y * u_stride;
+    out += (size_t)blockIdx.y * out_stride;
     uint32_t k = 0, rem = a.log_n, sh = 0;
     for (uint32_t d = 0; d < a.nd; ++d) {
         rem -= a.dig_bits[d];
@@ -203,10 +208,11 @@ __global__ __launch_bounds__(256) void coef_prepare_kernel(const uint32_t* U, ui
     out[pos] = mont_mul(v, mont_mul(pow_lookup(a.wtab, k), a.ninv_mont));
 }
 
-hipError_t launch_coef_prepare(const uint32_t* U, uint32_t* out, const CoefPrepArgs& a, hipStream_t s, Profiler* prof) {
+hipError_t launch_coef_prepare(const uint32_t* U, uint32_t* out, const CoefPrepArgs& a, hipStream_t s, Profiler* prof,
+                               uint32_t batch, size_t u_stride, size_t out_stride) {
     uint32_t n = 1u << a.log_n;
-    ScopedKernelTimer tm(prof, K_NTT, 8.0 * n, s);
-    hipLaunchKernelGGL(coef_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, U, out, a);
+    ScopedKernelTimer tm(prof, K_NTT, 8.0 * n * batch, s);
+    hipLaunchKernelGGL(coef_prepare_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, s, U, out, a, u_stride, out_stride);
     return hipGetLastError();
 }
 
@@ -286,21 +292,28 @@ hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uin
 //   p2 = (f(g^2 x) - f(g x)^2 - f(x)^2) (x - g^(n-3))(x - g^(n-2))(x - g^(n-1)) / (x^n - 1)
 //   cp = alpha0 p0 + alpha1 p1 + alpha2 p2
 // with f(g x_i) = f[i+B], f(g^2 x_i) = f[i+2B] (indices mod N); x^n - 1 depends on i mod B only.
-__device__ __forceinline__ uint32_t compose_at(const ComposeArgs& a, size_t i) {
+// BATCH: f and the trace / challenge constants belong to one proof of a batch, and a.zz carries no alpha2.
+template <bool BATCH>
+__device__ __forceinline__ uint32_t compose_core(const ComposeArgs& a, const uint32_t* f, uint32_t first, uint32_t last, uint32_t al0,
+                                                 uint32_t al1g2, uint32_t al2, size_t i) {
     const size_t N = (size_t)1 << a.logN;
     const uint32_t B = 1u << a.log_b;
     const size_t i1 = (i + B) & (N - 1), i2 = (i + 2 * (size_t)B) & (N - 1);
-    uint32_t f0 = a.f[i], f1 = a.f[i1], f2 = a.f[i2];
+    uint32_t f0 = f[i], f1 = f[i1], f2 = f[i2];
     uint32_t inv0 = a.inv_xm1[i], inv2 = a.inv_xm1[i2];
     uint32_t x = mont_mul(pow_lookup(a.htab, (uint32_t)i), a.w_mont);           // Montgomery x_i
-    uint32_t t0 = mont_mul(mont_mul(sub(f0, a.first), inv0), a.alpha0_mont);
-    uint32_t t1 = mont_mul(mont_mul(sub(f0, a.last), inv2), a.alpha1g2_mont);
+    uint32_t t0 = mont_mul(mont_mul(sub(f0, first), inv0), al0);
+    uint32_t t1 = mont_mul(mont_mul(sub(f0, last), inv2), al1g2);
     uint32_t v3 = mont_mul(mont_mul(sub(x, a.gm3_mont), sub(x, a.gm2_mont)), sub(x, a.gm1_mont));   // V*R
     uint32_t y = mont_mul(v3, a.zz[i & (B - 1)]);                                // alpha2 V / (x^n-1) * R^2
+    if (BATCH) y = mont_mul(y, al2);
     // data*data products carry R^-1; bring f2 to the same scale, fix with the R^2 in y
     uint32_t num = sub(sub(mont_mul(f2, 1u), mont_mul(f1, f1)), mont_mul(f0, f0));
     uint32_t t2 = mont_mul(num, y);
     return add(add(t0, t1), t2);
+}
+__device__ __forceinline__ uint32_t compose_at(const ComposeArgs& a, size_t i) {
+    return compose_core<false>(a, a.f, a.first, a.last, a.alpha0_mont, a.alpha1g2_mont, 0u, i);
 }
 
 __global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
@@ -387,6 +400,34 @@ struct FoldSrc {       // FRI layer r+1 = fold(layer r, beta): prover.rs:198-211
 struct ComposeSrc {    // cp layer 0 from f_eval: prover.rs:101-173 + :176
     ComposeArgs a;
     __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = compose_at(a, pos); a.cp[pos] = v; return v; }
+};
+
+struct ComposeBatchSrc {   // batch of proofs: leaf b*N + i = cp_b[i], with proof b's own challenges
+    ComposeArgs a;
+    const BatchChal* chal;
+    __device__ __forceinline__ uint32_t load(size_t pos) const {
+        const size_t b = pos >> a.logN, i = pos & (((size_t)1 << a.logN) - 1);
+        const BatchChal c = chal[b];
+        uint32_t v = compose_core<true>(a, a.f + (b << a.logN), c.first, c.last, c.alpha0_mont, c.alpha1g2_mont, c.alpha2_mont, i);
+        a.cp[pos] = v;
+        return v;
+    }
+};
+struct FoldBatchSrc {      // leaf b*(m/2) + i = fold of proof b's layer with its own beta
+    FoldArgs a;
+    const BatchChal* chal;
+    __device__ __forceinline__ uint32_t load(size_t pos) const {
+        const uint32_t lh = a.log_m - 1;
+        const size_t half = (size_t)1 << lh, b = pos >> lh, i = pos & (half - 1);
+        const uint32_t* in = a.in + (b << a.log_m);
+        uint32_t u = in[i], v = in[i + half];
+        uint32_t xinv = pow_lookup(a.hinv, (uint32_t)(i << a.round));
+        uint32_t s = mont_mul(add(u, v), a.inv2_mont);
+        uint32_t d = mont_mul(mont_mul(sub(u, v), xinv), chal[b].c_mont);
+        uint32_t r = add(s, d);
+        a.out[pos] = r;
+        return r;
+    }
 };
 
 struct InterleaveSrc { // leaves arrive as 2^log_parts cyclic pieces of 2^log_cnt words (multi-GPU all-to-all output):
@@ -759,6 +800,17 @@ hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStrea
     return merkle_build_t(ComposeSrc{a}, 8.0 * (double)((size_t)1 << a.logN), a.logN, nodes, s, prof, mail, hash);
 }
 
+hipError_t launch_compose_merkle_batch(const ComposeBatchArgs& a, uint32_t log_batch, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                                       const MailArgs& mail, int hash) {
+    uint32_t log_m = a.a.logN + log_batch;
+    return merkle_build_t(ComposeBatchSrc{a.a, a.chal}, 8.0 * (double)((size_t)1 << log_m), log_m, nodes, s, prof, mail, hash);
+}
+hipError_t launch_fold_merkle_batch(const FoldBatchArgs& a, uint32_t log_batch, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                                    const MailArgs& mail, int hash) {
+    uint32_t log_out = a.a.log_m - 1 + log_batch;
+    return merkle_build_t(FoldBatchSrc{a.a, a.chal}, 12.0 * (double)((size_t)1 << log_out), log_out, nodes, s, prof, mail, hash);
+}
+
 // Copies host-built pieces (tree tops, small layers) from the mapped staging buffer into the device
 // arrays so that the device state is complete after a proof (zk_merkle_path, zk_layer_read).
 __global__ __launch_bounds__(1024) void scatter_kernel(const uint32_t* stage, const ScatterSeg* segs, uint32_t* trees, uint32_t* layers) {
@@ -787,10 +839,10 @@ hipError_t launch_scatter(const uint32_t* stage, const ScatterSeg* segs, uint32_
 // prover.rs:32-39 is a serial recurrence, so one trace cannot be parallelised; many independent
 // traces can.  One lane per trace: out[t*count + i] = a_i of trace t (a0[t], a1[t] seeds).
 __global__ __launch_bounds__(64) void trace_fibsq_batch_kernel(const uint32_t* a0, const uint32_t* a1, uint32_t batch,
-                                                               uint32_t count, uint32_t* out) {
+                                                               uint32_t count, uint32_t* out, uint32_t stride) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= batch) return;
-    uint32_t* row = out + (size_t)t * count;
+    uint32_t* row = out + (size_t)t * stride;
     // Montgomery domain: squares of Montgomery values stay Montgomery
     uint32_t x = mont_mul(a0[t], R2_MONT), y = mont_mul(a1[t], R2_MONT);
     if (count > 0) row[0] = mont_mul(x, 1u);
@@ -802,9 +854,10 @@ __global__ __launch_bounds__(64) void trace_fibsq_batch_kernel(const uint32_t* a
     }
 }
 
-hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s) {
+hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s,
+                                    uint32_t stride) {
     if (!batch) return hipSuccess;
-    hipLaunchKernelGGL(trace_fibsq_batch_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, a0, a1, batch, count, out);
+    hipLaunchKernelGGL(trace_fibsq_batch_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, a0, a1, batch, count, out, stride ? stride : count);
     return hipGetLastError();
 }
 

@@ -82,6 +82,9 @@ struct NttPassArgs {
     uint32_t L;           // the table root has order 2^L
     PowTable tw;          // h (forward) or h^-1 (inverse)
     uint32_t scale_mont;  // NTT_DIF only: multiply outputs by this Montgomery constant when S == 1 (n^-1); 0 = none
+    // batch of independent transforms (zk_batch_*): grid.y = batch, transform b at src + b*src_stride / dst + b*dst_stride
+    uint32_t batch;       // 0 or 1 = a single transform
+    size_t src_stride, dst_stride;
 };
 
 struct CoefPrepArgs {
@@ -92,7 +95,9 @@ struct CoefPrepArgs {
     uint32_t nd;          // storage digits of the coefficient array, slowest first
     uint32_t dig_bits[kMaxDigits];
 };
-hipError_t launch_coef_prepare(const uint32_t* U, uint32_t* out, const CoefPrepArgs& a, hipStream_t s, Profiler* prof = nullptr);
+// batch > 1: transform b reads U + b*u_stride and writes out + b*out_stride
+hipError_t launch_coef_prepare(const uint32_t* U, uint32_t* out, const CoefPrepArgs& a, hipStream_t s, Profiler* prof = nullptr,
+                               uint32_t batch = 1, size_t u_stride = 0, size_t out_stride = 0);
 
 hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Profiler* prof = nullptr);
 // out[pos] = in[true_index(pos)] for the mixed-radix digit reversal (standalone NTT API only)
@@ -165,8 +170,25 @@ hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s,
 hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                                  const MailArgs& mail = MailArgs{}, int hash = 0);
 
-// batch traces of prover.rs:32-39, one lane per trace: out[t*count + i]
-hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s);
+// ---- batched proving: 2^log_batch proofs of one size in lockstep ------------------
+// Layer l of the batch is stored proof-major, [batch][m_l]; the 2^log_batch trees over it are the bottom of
+// ONE tree over batch*m_l leaves, whose nodes of depth log_batch are the per-proof roots (MailArgs.top).
+struct BatchChal {              // per proof, derived from its own transcript (device array)
+    uint32_t first, last;       // a[0], a[n-2] canonical
+    uint32_t alpha0_mont, alpha1g2_mont, alpha2_mont;
+    uint32_t c_mont;            // this round's beta * w^(-2^r) / 2
+    uint32_t pad[2];
+};
+struct ComposeBatchArgs { ComposeArgs a; const BatchChal* chal; };   // a.f, a.cp: [batch][N]; a.zz: R^2 / (x^n - 1), no alpha2
+struct FoldBatchArgs { FoldArgs a; const BatchChal* chal; };         // a.in: [batch][m], a.out: [batch][m/2]
+hipError_t launch_compose_merkle_batch(const ComposeBatchArgs& a, uint32_t log_batch, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                                       const MailArgs& mail, int hash);
+hipError_t launch_fold_merkle_batch(const FoldBatchArgs& a, uint32_t log_batch, uint32_t* nodes, hipStream_t s, Profiler* prof,
+                                    const MailArgs& mail, int hash);
+
+// batch traces of prover.rs:32-39, one lane per trace: out[t*stride + i], i < count (stride 0 = count)
+hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s,
+                                    uint32_t stride = 0);
 
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,

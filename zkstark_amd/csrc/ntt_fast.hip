@@ -88,6 +88,8 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     constexpr int LOGC = (int)kTileLog - LOGR, C = 1 << LOGC;
     constexpr int PITCH = STAGED || MODE == NTT_DIT_LDE ? C + 1 : C;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    p.src += (size_t)blockIdx.y * p.src_stride;      // batch of independent transforms
+    p.dst += (size_t)blockIdx.y * p.dst_stride;
     uint32_t* tile = smem;                    // R * PITCH
     uint32_t* twl = smem + R * PITCH;         // w_R^e, e < R
     const uint32_t tid = threadIdx.x;
@@ -210,8 +212,9 @@ template <uint32_t MODE, int LA, int LB>
 hipError_t launch2(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
     constexpr int R = 1 << (LA + LB), C = 1 << ((int)kTileLog - LA - LB);
     size_t shmem = ((size_t)R * (C + 1) + R) * sizeof(uint32_t);
-    if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true>), dim3(blocks), dim3(kThreads), shmem, s, a);
-    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false>), dim3(blocks), dim3(kThreads), shmem, s, a);
+    const dim3 grid(blocks, a.batch ? a.batch : 1);
+    if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true>), grid, dim3(kThreads), shmem, s, a);
+    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false>), grid, dim3(kThreads), shmem, s, a);
     return hipGetLastError();
 }
 

@@ -307,6 +307,62 @@ class Context:
         return info
 
 
+class BatchContext:
+    """2^log_batch proofs of one size in lockstep (zk_batch_*): every stage is one
+    launch over the whole batch; each proof has its own channel and is byte-identical to Context.prove()."""
+
+    def __init__(self, log_n=10, log_blowup=3, log_batch=4, device=0):
+        self.log_n, self.log_blowup, self.log_batch = log_n, log_blowup, log_batch
+        self.n, self.batch = 1 << log_n, 1 << log_batch
+        self._h = C.c_void_p()
+        check(_lib.load().zk_batch_create(device, log_n, log_blowup, log_batch, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().zk_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    @property
+    def device_bytes(self): return _lib.load().zk_batch_device_bytes(self._h)
+
+    def set_traces(self, traces):
+        """traces: [batch][n-1] canonical residues."""
+        t = np.ascontiguousarray(traces, dtype=np.uint32)
+        if t.shape != (self.batch, self.n - 1):
+            raise ZkError(-1, f"expected traces of shape ({self.batch}, {self.n - 1})")
+        check(_lib.load().zk_batch_set_traces(self._h, _ptr(t)))
+
+    def gen_fibsq(self, a0s, a1s):
+        """prover.rs:32-39 for every proof, on the device, from the seeds a0s[p], a1s[p]."""
+        a0, a1 = _u32arr(a0s), _u32arr(a1s)
+        if len(a0) != self.batch or len(a1) != self.batch:
+            raise ZkError(-1, f"expected {self.batch} seeds")
+        check(_lib.load().zk_batch_gen_fibsq(self._h, _ptr(a0), _ptr(a1)))
+
+    def public_last(self):
+        out = np.zeros(self.batch, dtype=np.uint32)
+        check(_lib.load().zk_batch_public_last(self._h, _ptr(out)))
+        return out
+
+    def prove_raw(self):
+        """Returns (proof bytes [batch][len] as a uint8 array, states [batch][32])."""
+        plen = _lib.load().zk_proof_data_len(self.log_n, self.log_blowup)
+        data = np.zeros((self.batch, plen), dtype=np.uint8)
+        states = np.zeros((self.batch, 32), dtype=np.uint8)
+        check(_lib.load().zk_batch_prove(self._h, data.ctypes.data_as(C.c_void_p), plen, states.ctypes.data_as(C.c_void_p)))
+        return data, states
+
+    def prove(self):
+        data, states = self.prove_raw()
+        last = self.public_last()
+        return [Proof(states[p].tobytes(), data[p].tobytes(), self.log_n, self.log_blowup, int(last[p])) for p in range(self.batch)]
+
+
 def generate_proof(channel, log_n=10, log_blowup=3, a0=1, a1=3141592, ctx=None):
     """prover.rs:9-293, stage by stage over the C ABI, driven by `channel`.
 
