@@ -174,7 +174,7 @@ hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Pr
     double bytes = mode == NTT_DIT_LDE ? 4.0 * ((double)((size_t)1 << (a.log_total - a.logS)) + (double)((size_t)1 << a.log_total))
                                        : 8.0 * (double)((size_t)1 << a.log_total);
     const uint32_t batch = a.batch ? a.batch : 1;
-    ScopedKernelTimer tm(prof, K_NTT, bytes * batch, s);
+    ScopedKernelTimer tm(prof, K_NTT, bytes * batch, s, kNttOpsPerElement * (double)((size_t)1 << a.log_total) * batch * (double)a.logR / 7.0);
     hipError_t ferr = hipSuccess;
     if (launch_ntt_pass_fast(a, mode, s, &ferr)) return ferr;
     uint32_t cols_log = a.log_total - a.logR;

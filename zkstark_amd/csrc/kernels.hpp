@@ -25,6 +25,7 @@ enum KernelClass : int {
 
 constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
 constexpr double kShaInnerOps = 2293.0;
+constexpr double kNttOpsPerElement = 78.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU: 2456-2560 per wave of 32 elements/lane)
 constexpr double kFieldLeafOps = 10200.0;   // field-native hash, one permutation (estimate from timing at equal VALU efficiency, +-5 %)
 constexpr double kFieldInnerOps = 10300.0;   // ... of one inner hash (two compressions, second with constant schedule)
 
