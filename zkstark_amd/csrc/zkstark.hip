@@ -445,8 +445,11 @@ int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream) {
     uint64_t spins = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
         if ((++spins & 0xFFFF) == 0) {
-            if (hipStreamQuery(stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
+            hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
                 return fail(ZK_ERR_HIP, "merkle digests were never posted (stream drained)");
+            if (q != hipSuccess && q != hipErrorNotReady)
+                return fail(ZK_ERR_HIP, "device error while waiting for merkle digests: %s", hipGetErrorString(q));
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
                 return fail(ZK_ERR_HIP, "timed out waiting for merkle digests");
         }
