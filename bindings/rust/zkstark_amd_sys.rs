@@ -2,6 +2,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
+#[repr(C)] pub struct zk_batch { _private: [u8; 0] }
 #[repr(C)] pub struct zk_ctx { _private: [u8; 0] }
 #[repr(C)] pub struct zk_dom { _private: [u8; 0] }
 #[repr(C)] pub struct zk_channel { _private: [u8; 0] }
@@ -62,4 +63,16 @@ extern "C" {
     pub fn zk_merkle_build_host(device: c_int, vals: *const u32, m: usize, nodes_out: *mut u8) -> c_int;
     // device-pointer primitives
     pub fn zk_dev_merkle_build(d_vals: *const u32, log_m: u32, d_nodes: *mut u32, stream: *mut c_void) -> c_int;
+    // settings of the one-call prover
+    pub fn zk_ctx_set_queries(ctx: *mut zk_ctx, n_queries: u32) -> c_int;
+    pub fn zk_ctx_set_hash(ctx: *mut zk_ctx, hash_kind: c_int) -> c_int;
+    pub fn zk_ctx_set_host_levels(ctx: *mut zk_ctx, top_log: u32, tail_log: u32) -> c_int;
+    // batched proving: 2^log_batch proofs of one size in lockstep (prover.rs:9-293 each)
+    pub fn zk_batch_create(device: c_int, log_n: u32, log_blowup: u32, log_batch: u32, out: *mut *mut zk_batch) -> c_int;
+    pub fn zk_batch_destroy(b: *mut zk_batch) -> c_int;
+    pub fn zk_batch_size(b: *const zk_batch) -> usize;
+    pub fn zk_batch_set_traces(b: *mut zk_batch, traces: *const u32) -> c_int;
+    pub fn zk_batch_gen_fibsq(b: *mut zk_batch, a0: *const u32, a1: *const u32) -> c_int;
+    pub fn zk_batch_public_last(b: *const zk_batch, out: *mut u32) -> c_int;
+    pub fn zk_batch_prove(b: *mut zk_batch, proofs_out: *mut u8, stride: usize, states_out: *mut u8) -> c_int;
 }
