@@ -344,6 +344,25 @@ def test_c_abi_from_plain_c(tmp_path):
     assert "final state: " + " ".join(canon["final_state"][2 * i:2 * i + 2] for i in range(8)) in out.stdout
 
 
+def test_batch_c_abi_from_plain_c(tmp_path):
+    """examples/batch_c_abi.c: 64 proofs of the reference's size in one zk_batch_prove, each accepted by the
+    verifier; proof 0 (the reference's own trace) starts with the golden proof's bytes."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "batch_c_abi")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "batch_c_abi.c"),
+                           "-L" + os.path.join(root, "zkstark_amd"), "-lzkstark_amd",
+                           "-Wl,-rpath," + os.path.join(root, "zkstark_amd"), "-o", exe])
+    out = subprocess.run([exe, "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    canon = json.load(open(os.path.join(root, "tests", "golden", "stark101_canonical.json")))["derived"]
+    assert "a[n-2] of proof 0 = 2338775057" in out.stdout
+    assert "all 64 proofs verified; proof size 7884" in out.stdout
+    assert "proof 0 head: " + " ".join(canon["proof_hex"][2 * i:2 * i + 2] for i in range(8)) in out.stdout
+
+
 @pytest.mark.parametrize("log_m", [4, 10, 14])
 def test_ntt_edge_values(zk, orc, log_m):
     """Field edge cases through the butterflies: 0, 1, P-1 (a + b overflows u32 since P > 2^31), deltas, constants."""
