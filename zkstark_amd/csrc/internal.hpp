@@ -1,0 +1,103 @@
+// internal.hpp -- shared between the translation units of the host side (domain.hip, zkstark.hip,
+// batch.hip).  Not part of the C ABI (include/zkstark_amd.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/zkstark_amd.h"
+#include "field.hpp"
+#include "kernels.hpp"
+
+namespace zk {
+namespace impl {
+
+// error reporting of the C ABI: every entry point returns fail(code, ...) and zk_last_error() hands the text out
+int fail(int code, const char* fmt, ...);
+const char* last_error();
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ::zk::impl::fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr uint32_t kMaxQueries = 64;
+constexpr uint32_t kMaxHostLog = 10;                         // host_top, host_tail, log_batch <= 10
+constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // after the digests of depth host_top
+constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail
+constexpr uint32_t kTileLog = 13;      // 8192 words = 32 KiB per workgroup tile
+constexpr uint32_t kMaxRadixLog = 8;
+
+// ---- transform plan: the size-2^log_m transform as radix-2^bits[d] passes, d = 0 the slowest storage digit
+struct Plan {
+    uint32_t nd = 0;
+    uint32_t bits[kMaxDigits] = {0};
+};
+Plan make_plan(uint32_t log_m);
+uint32_t pick_logC(uint32_t log_total, uint32_t logR);
+
+// ---- two-level power tables on the device
+struct DevTable {
+    uint32_t* lo = nullptr;
+    uint32_t* hi = nullptr;
+    uint32_t lo_bits = 0;
+    PowTable view() const { return PowTable{lo, hi, lo_bits}; }
+};
+int build_table(uint32_t root, uint32_t log_order, DevTable* t);
+void free_table(DevTable* t);
+
+// Inverse transform, natural order in, digit-reversed out, optionally scaled by scale_mont.
+int run_dif(const uint32_t* src, uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw_inv, uint32_t L, uint32_t scale_mont,
+            hipStream_t s, Profiler* prof = nullptr, uint32_t batch = 1, size_t src_stride = 0, size_t data_stride = 0);
+// Forward transform, digit-reversed in, natural out.
+int run_dit(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw, uint32_t L, hipStream_t s);
+
+}  // namespace impl
+}  // namespace zk
+
+// ===========================================================================
+// Coset evaluation domain: {shift * h^i, i < N}, h = root_of_unity(log_n + log_b)
+// ===========================================================================
+// Everything the kernels need that depends only on (log_n, log_b, shift): power tables,
+// the 1/(x-1) table, the transform plan and Montgomery constants.  The reference's
+// domain is shift = w = 5 (prover.rs:69).  A shard of a multi-GPU proof is the same
+// structure with shift = w * h_global^rank and a smaller blow-up.
+struct zk_dom {
+    int device = 0;
+    uint32_t log_n = 0, log_b = 0, L = 0;
+    size_t n = 0, N = 0, B = 0;
+    uint32_t shift = 0, g = 0, h = 0;
+    zk::impl::DevTable H, Hinv, W;
+    uint32_t* d_inv_xm1 = nullptr;   // null for fold-only domains
+    zk::impl::Plan plan;
+    uint32_t shift_mont = 0, gm1_mont = 0, gm2_mont = 0, gm3_mont = 0, ninv_mont = 0, inv2_mont = 0;
+    size_t device_bytes = 0;
+};
+
+namespace zk {
+namespace impl {
+
+void dom_free(zk_dom* d);
+// fold_only: tables for fri_fold only (no w-power table, no 1/(x-1) table)
+int dom_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool fold_only, hipStream_t stream, zk_dom** out);
+// lagrange + solve over the coset (polynomial.rs:337, :49; prover.rs:60-70); batch > 1: proof b at
+// d_trace + b*n, d_coef + b*2n, d_out + b*N
+int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t* d_out, hipStream_t s, Profiler* prof, uint32_t batch = 1);
+int compose_args(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last, const uint32_t alpha_raw[3], ComposeArgs& a);
+int dom_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last, const uint32_t alpha_raw[3],
+                hipStream_t s, Profiler* prof);
+int fold_args(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw, FoldArgs& a);
+int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw, hipStream_t s,
+             Profiler* prof);
+
+// Waits until *flag (host-mapped memory written by a commit launch on `stream`) equals `want`.
+int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream);
+double now_us();
+// merkle.rs:54-71: node indices of the authentication path of `leaf` in a tree of m leaves
+void path_nodes(size_t m, size_t leaf, std::vector<size_t>& out);
+
+}  // namespace impl
+}  // namespace zk
