@@ -298,6 +298,9 @@ int zk_committer_create(int device, zk_committer **out);
 int zk_committer_destroy(zk_committer *k);
 int zk_dev_merkle_commit(zk_committer *k, const uint32_t *d_src, uint32_t log_parts, uint32_t log_cnt,
                          uint32_t *d_nodes, void *stream, int hash_kind, uint8_t root_out[32]);
+/* zk_dev_merkle_finish with the same hand-over: for a tree built with zk_dev_merkle_build_chunk. */
+int zk_dev_merkle_commit_finish(zk_committer *k, uint32_t *d_nodes, uint32_t log_m, uint32_t log_chunks,
+                                void *stream, int hash_kind, uint8_t root_out[32]);
 /* The same tree in 2^c aligned chunks, so that hashing chunk i overlaps the exchange of chunk i+1: chunk
  * `chunk` covers leaves [chunk << s, (chunk+1) << s), s = log_parts + log_cnt, arriving in its own
  * receive buffer in all-to-all order; the throughput-bound levels are built in place in the heap over

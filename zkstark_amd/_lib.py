@@ -97,6 +97,7 @@ SYMBOLS = {
     "zk_committer_create": (_int, [_int, C.POINTER(_vp)]),
     "zk_committer_destroy": (_int, [_vp]),
     "zk_dev_merkle_commit": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _int, _vp]),
+    "zk_dev_merkle_commit_finish": (_int, [_vp, _vp, _u32, _u32, _vp, _int, _vp]),
     "zk_dev_merkle_finish": (_int, [_vp, _u32, _u32, _vp, _int]),
     "zk_verify_strict": (_int, [_vp, _sz, _vp, _u32, _u32, _u32]),
     "zk_proof_size": (_sz, [_sz]),

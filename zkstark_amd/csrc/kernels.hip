@@ -775,6 +775,7 @@ static uint32_t chunk_handover_depth(uint32_t log_m, uint32_t log_chunks) {
     const uint32_t lat = merkle_latency_log();
     return (log_m > lat && lat >= log_chunks + 8) ? lat : log_chunks;
 }
+uint32_t merkle_finish_start_depth(uint32_t log_m, uint32_t log_chunks) { return chunk_handover_depth(log_m, log_chunks); }
 hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, uint32_t log_m,
                                      uint32_t chunk, hipStream_t s, Profiler* prof, int hash) {
     uint32_t log_sub = log_parts + log_cnt;
@@ -784,11 +785,12 @@ hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, u
 }
 // After every chunk of a 2^log_m-leaf tree (2^log_chunks chunks) has been built down to the switch depth:
 // the latency phase of the whole tree, once.
-hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof, int hash) {
+hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof, int hash,
+                                const MailArgs& mail) {
     const uint32_t start = chunk_handover_depth(log_m, log_chunks);   // depth the chunk builds stopped at
     if (start == 0) return hipSuccess;
     // the nodes at depth `start` exist: inner mode over a "tree" of 2^start inputs shares the top of the heap
-    return merkle_build_t(PlainSrc{nullptr}, 0.0, start, nodes, s, prof, MailArgs{}, hash, start, 0, false);
+    return merkle_build_t(PlainSrc{nullptr}, 0.0, start, nodes, s, prof, mail, hash, start, 0, false);
 }
 // fold + commit of the folded layer (a.out receives it): one pass
 hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof, const MailArgs& mail, int hash) {

@@ -164,7 +164,10 @@ hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_pa
                                            Profiler* prof = nullptr, int hash = 0, const MailArgs& mail = MailArgs{});
 hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, uint32_t log_m,
                                      uint32_t chunk, hipStream_t s, Profiler* prof = nullptr, int hash = 0);
-hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof = nullptr, int hash = 0);
+// depth at which the chunk builds of a 2^log_m-leaf tree stop and launch_merkle_finish takes over
+uint32_t merkle_finish_start_depth(uint32_t log_m, uint32_t log_chunks);
+hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof = nullptr, int hash = 0,
+                                const MailArgs& mail = MailArgs{});
 // Fused producer + commitment: the layer is computed, stored and leaf-hashed in one pass.
 hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                               const MailArgs& mail = MailArgs{}, int hash = 0);

@@ -994,6 +994,24 @@ int zk_committer_create(int device, zk_committer** out) {
     *out = k;
     return ZK_OK;
 }
+// Waits for the digests a commit launch posted; with a hand-over depth, hashes the levels above on this thread
+// and queues the copy of those nodes into d_nodes.
+static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nodes, hipStream_t s, uint8_t root_out[32]) {
+    int rc = wait_flag(k->h_mail, m.seq, s);
+    if (rc) return rc;
+    if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
+    const size_t cnt = (size_t)1 << m.top;
+    uint32_t* nodes = k->h_stage;
+    memcpy(nodes + 8 * (cnt - 1), k->h_mail + kMailDigests, cnt * 32);
+    host_sha_reduce(nodes, m.top);
+    digest_words_to_bytes(nodes, root_out);
+    ScatterSeg* seg = reinterpret_cast<ScatterSeg*>(k->h_stage + ((size_t)16 << kMaxHostLog));
+    *seg = ScatterSeg{0, 0, (uint32_t)((cnt - 1) * 8), 0};
+    HIPCHK(launch_scatter(k->d_stage, reinterpret_cast<ScatterSeg*>(k->d_stage + ((size_t)16 << kMaxHostLog)), 1, (double)seg->words,
+                          d_nodes, nullptr, s, dev_prof()));
+    return ZK_OK;
+}
+
 // Tree over 2^(log_parts + log_cnt) leaves (log_parts = 0: d_src in natural order; else in all-to-all order as
 // for zk_dev_merkle_build_interleaved), root returned to the host.  The device stops at depth `top`, the calling
 // thread hashes the levels above and a stream-ordered copy completes d_nodes (merkle.rs:14-51 either way).
@@ -1011,19 +1029,25 @@ int zk_dev_merkle_commit(zk_committer* k, const uint32_t* d_src, uint32_t log_pa
     m.top = (hash_kind == 0 && k->top && log_m > k->top) ? k->top : 0;
     if (log_parts) HIPCHK(launch_merkle_build_interleaved(d_src, log_parts, log_cnt, d_nodes, s, dev_prof(), hash_kind, m));
     else HIPCHK(launch_merkle_build(d_src, log_m, d_nodes, s, dev_prof(), m, hash_kind));
-    int rc = wait_flag(k->h_mail, m.seq, s);
-    if (rc) return rc;
-    if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
-    const size_t cnt = (size_t)1 << m.top;
-    uint32_t* nodes = k->h_stage;
-    memcpy(nodes + 8 * (cnt - 1), k->h_mail + kMailDigests, cnt * 32);
-    host_sha_reduce(nodes, m.top);
-    digest_words_to_bytes(nodes, root_out);
-    ScatterSeg* seg = reinterpret_cast<ScatterSeg*>(k->h_stage + ((size_t)16 << kMaxHostLog));
-    *seg = ScatterSeg{0, 0, (uint32_t)((cnt - 1) * 8), 0};
-    HIPCHK(launch_scatter(k->d_stage, reinterpret_cast<ScatterSeg*>(k->d_stage + ((size_t)16 << kMaxHostLog)), 1, (double)seg->words,
-                          d_nodes, nullptr, s, dev_prof()));
-    return ZK_OK;
+    return committer_collect(k, m, d_nodes, s, root_out);
+}
+
+// The same hand-over for a tree built in chunks (zk_dev_merkle_build_chunk): the latency-bound top of the
+// whole tree down to depth `top` on the device, the rest on the calling thread, root returned.
+int zk_dev_merkle_commit_finish(zk_committer* k, uint32_t* d_nodes, uint32_t log_m, uint32_t log_chunks, void* stream, int hash_kind,
+                                uint8_t root_out[32]) {
+    if (!k || !d_nodes || !root_out || log_m > 30 || log_chunks > 10 || log_chunks > log_m || (hash_kind != 0 && hash_kind != 1))
+        return fail(ZK_ERR_INVALID, "zk_dev_merkle_commit_finish: bad argument");
+    HIPCHK(hipSetDevice(k->device));
+    hipStream_t s = (hipStream_t)stream;
+    MailArgs m;
+    m.mailbox = k->d_mail;
+    m.seq = ++k->seq;
+    m.counter = k->d_counter;
+    // the finish pass starts at the hand-over depth of the chunk builds; the host takes over only below that
+    m.top = (hash_kind == 0 && k->top && merkle_finish_start_depth(log_m, log_chunks) > k->top) ? k->top : 0;
+    HIPCHK(launch_merkle_finish(d_nodes, log_m, log_chunks, s, dev_prof(), hash_kind, m));
+    return committer_collect(k, m, d_nodes, s, root_out);
 }
 
 int zk_dev_merkle_build_chunk(const uint32_t* d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* d_nodes, uint32_t log_m,

@@ -106,6 +106,14 @@ class Comm:
             return None
         return self.dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
+    def lists_ok(self):
+        """True when the backend exchanges lists of (non-contiguous) slices in place: RCCL does, gloo does not."""
+        return not self.staged and self.dist.get_backend(self.group) == "nccl"
+
+    def all_to_all_list_async(self, sends, recvs):
+        """sends[p] goes to rank p, recvs[q] comes from rank q (any slices of device tensors, no packing)."""
+        return self.dist.all_to_all(recvs, sends, group=self.group, async_op=True)
+
     def all_gather(self, t, out):
         """out: [world * len(t)] flat."""
         if self.staged and t.is_cuda:
@@ -267,14 +275,23 @@ class HipBackend:
     def merkle_finish(self, nodes, log_m, log_chunks):
         check(self.lib.zk_dev_merkle_finish(nodes.data_ptr(), log_m, log_chunks, self._stream(), 0))
 
-    def commit(self, src, log_parts, log_cnt, nodes):
-        """Tree over 2^(log_parts+log_cnt) leaves (log_parts > 0: still in all-to-all order) with the root
-        returned as bytes: the device stops at depth 8, this thread hashes the top (zk_dev_merkle_commit)."""
+    def _committer_handle(self):
         if getattr(self, "_committer", None) is None:
             self._committer = C.c_void_p()
             check(self.lib.zk_committer_create(self.index, C.byref(self._committer)))
+        return self._committer
+
+    def commit_finish(self, nodes, log_m, log_chunks):
+        """merkle_finish with the root returned as bytes (top of the tree on this thread)."""
         root = C.create_string_buffer(32)
-        check(self.lib.zk_dev_merkle_commit(self._committer, src.data_ptr(), log_parts, log_cnt, nodes.data_ptr(), self._stream(), 0, root))
+        check(self.lib.zk_dev_merkle_commit_finish(self._committer_handle(), nodes.data_ptr(), log_m, log_chunks, self._stream(), 0, root))
+        return root.raw
+
+    def commit(self, src, log_parts, log_cnt, nodes):
+        """Tree over 2^(log_parts+log_cnt) leaves (log_parts > 0: still in all-to-all order) with the root
+        returned as bytes: the device stops at depth 8, this thread hashes the top (zk_dev_merkle_commit)."""
+        root = C.create_string_buffer(32)
+        check(self.lib.zk_dev_merkle_commit(self._committer_handle(), src.data_ptr(), log_parts, log_cnt, nodes.data_ptr(), self._stream(), 0, root))
         return root.raw
 
     def merkle_interleaved(self, recv, log_parts, log_cnt, nodes):
@@ -294,6 +311,20 @@ class HipBackend:
 
     def sync(self):
         self.torch.cuda.current_stream(self.device).synchronize()
+
+    def side_begin(self):
+        """A second stream, ordered after everything queued so far on the current one."""
+        torch = self.torch
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._side.wait_event(ev)
+        return self._side
+
+    def on_side(self, fn):
+        with self.torch.cuda.stream(self._side):
+            return fn()
 
     # FRI tail in one C call (zk_tail_*): the replicated small layers need no collectives, so the
     # per-round Python and readback cost is dropped for them
@@ -425,16 +456,38 @@ class ShardedProver:
             # all-to-all of chunk c+1 (the exchange runs on RCCL's stream)
             K, lk = 1 << self.log_chunks, self.log_chunks
             cc = cnt >> (lg + lk)                                 # words per (peer, chunk)
-            send = self.block[:cnt]
-            send.view(K, G, cc).copy_(loc.view(G, K, cc).transpose(0, 1))     # pack: chunk-major
-            works = [self.comm.all_to_all_async(send[c * G * cc:(c + 1) * G * cc], recv[c * G * cc:(c + 1) * G * cc])
-                     for c in range(K)]
+            per = cnt >> lg                                       # words this rank holds for each peer
+            lists = hasattr(self.comm, "lists_ok") and self.comm.lists_ok()
+            if not lists:                                         # backends without list exchange: pack chunk-major first
+                send = self.block[:cnt]
+                send.view(K, G, cc).copy_(loc.view(G, K, cc).transpose(0, 1))
+            # the exchanges are issued from a side stream that depends on the layer only, so a chunk's exchange
+            # never queues behind the hashing of an earlier chunk; issue order keeps two exchanges ahead
+            side = be.side_begin() if hasattr(be, "side_begin") and not getattr(self.comm, "staged", False) else None
+            works = [None] * K
+
+            def exchange(c):
+                if lists:
+                    return self.comm.all_to_all_list_async([loc[g * per + c * cc:g * per + (c + 1) * cc] for g in range(G)],
+                                                           [recv[(c * G + q) * cc:(c * G + q + 1) * cc] for q in range(G)])
+                sl = slice(c * G * cc, (c + 1) * G * cc)
+                return self.comm.all_to_all_async(send[sl], recv[sl])
+
+            def post(c):
+                works[c] = be.on_side(lambda: exchange(c)) if side is not None else exchange(c)
+            for c in range(min(2, K)):
+                post(c)
             for c in range(K):
                 if works[c] is not None:
                     works[c].wait()
                 be.merkle_chunk(recv[c * G * cc:(c + 1) * G * cc], lg, log_cnt - lk, nodes, m_log - lg, c)
-            be.merkle_finish(nodes, m_log - lg, lk)
-            mine = None
+                if c + 2 < K:
+                    post(c + 2)
+            if hasattr(be, "commit_finish"):
+                mine = be.commit_finish(nodes, m_log - lg, lk)
+            else:
+                be.merkle_finish(nodes, m_log - lg, lk)
+                mine = None
         elif G > 1 or self.comm.force:
             self.comm.all_to_all(loc, recv)                       # chunk q: rank q's j in my block
             mine = None
