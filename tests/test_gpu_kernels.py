@@ -498,3 +498,31 @@ def test_batch_prover_rejects_a_bad_trace(zk):
         zk.BatchContext(10, 3, 11)
     with pytest.raises(zk.ZkError):
         zk.BatchContext(10, 0, 2)
+
+
+def test_maximum_domain_2e30(zk):
+    """The largest domain the field admits (n * B must divide 2^30; SURVEY 8: N <= 2^30): 225 GB of layers and
+    full trees on one MI355X.  No oracle at this size: two proofs from one resident trace are identical and the
+    transcript-replaying verifier accepts (proof.rs:15-149 generalised)."""
+    import torch
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 232 * 10**9:
+        pytest.skip(f"needs 232 GB of free device memory, {free / 1e9:.0f} GB available")
+    log_n = 27
+    try:
+        ctx = zk.Context(log_n, 3)
+    except zk.ZkError as e:
+        if e.code == -3:
+            pytest.skip("device memory exhausted")
+        raise
+    with ctx:
+        ctx.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        p = ctx.prove()
+        q = ctx.prove()
+        assert ctx.device_bytes > 200 * 10**9
+    assert p.data == q.data and p.state == q.state
+    assert len(p.data) == 34968
+    p.verify(strict=True)
+    with pytest.raises(zk.ZkError):
+        zk.Context(28, 3)                                    # n * B = 2^31 does not divide P - 1 = 3 * 2^30
