@@ -275,6 +275,7 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
     const uint32_t R = b->R, L = b->L, lb = b->lb;
     const zk_dom* d = b->dom;
     std::vector<Channel> ch(nb);
+    for (auto& c : ch) c.data.reserve(plen);
     int rc;
     static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
     double T0 = now_us(), t_wait = 0;

@@ -304,6 +304,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     const uint32_t R = c->R;
     const size_t B = c->B, N = c->N;
     Channel ch;                                          // main.rs:19
+    ch.data.reserve(proof_data_len(c->log_n, c->log_b, c->queries));
     uint8_t root[32];
     int rc;
     memset(&c->info, 0, sizeof c->info);
