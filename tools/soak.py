@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import zkstark_amd as zk
 
 t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 60
-count = {"big": 0, "small": 0, "batch": 0, "mid": 0}
+count = {"big": 0, "small": 0, "batch": 0, "mid": 0, "sharded": 0}
 err = []
 
 def loop(name, make, prove):
@@ -32,7 +32,14 @@ def mk_batch():
     b.gen_fibsq([1] * 256, [7 + p for p in range(256)])
     return b
 
-th = [threading.Thread(target=loop, args=("big", mk_ctx(21), lambda c: c.prove().data)),
+def mk_sharded():
+    from zkstark_amd import sharded
+    sp = sharded.ShardedProver(17, 3, sharded.LocalComm(), sharded.HipBackend(0), min_chunk_log=8)
+    sp.trace_upload(zk.trace_fibsq((1 << 17) - 1))
+    return sp
+
+th = [threading.Thread(target=loop, args=("sharded", mk_sharded, lambda sp: sp.prove().data)),
+      threading.Thread(target=loop, args=("big", mk_ctx(21), lambda c: c.prove().data)),
       threading.Thread(target=loop, args=("mid", mk_ctx(16, (7, 8)), lambda c: c.prove().data)),
       threading.Thread(target=loop, args=("small", mk_ctx(10), lambda c: c.prove().data)),
       threading.Thread(target=loop, args=("batch", mk_batch, lambda b: b.prove_raw()[0].tobytes()))]
