@@ -130,6 +130,15 @@ def test_compute_calls_fail_loudly_without_gpu(zk):
         zk.Merkle.new(4, [1, 2, 3, 4])
     with pytest.raises(zk.ZkError):
         zk.ntt([1, 2, 3, 4])
+    with pytest.raises(zk.ZkError):
+        zk.BatchContext(6, 2, 2)
+    with pytest.raises(zk.ZkError):
+        zk.trace_fibsq_batch([1, 1], [3, 4], 63)
+    import ctypes as C
+    from zkstark_amd import _lib
+    h = C.c_void_p()
+    assert _lib.load().zk_committer_create(0, C.byref(h)) < 0 and not h.value
+    assert _lib.load().zk_dom_create(0, 6, 2, 5, 0, C.byref(h)) < 0 and not h.value
 
 
 def test_context_argument_checks(zk):
