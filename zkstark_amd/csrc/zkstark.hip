@@ -229,14 +229,14 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     if (!vals || !nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
     const zk_dom* d = c->dom;
     const uint32_t inv2 = invmod(2);
-    const uint32_t cc = mulmod(mulmod(beta_raw % P, invmod(powmod(d->shift, (uint64_t)1 << round))), inv2);   // beta / (2 w^(2^r))
-    const uint32_t step = powmod(invmod(d->h), (uint64_t)1 << round);                                        // h^(-2^r)
+    const uint32_t cc_m = to_mont(mulmod(mulmod(beta_raw % P, invmod(powmod(d->shift, (uint64_t)1 << round))), inv2));   // beta / (2 w^(2^r))
+    const uint32_t step_m = to_mont(powmod(invmod(d->h), (uint64_t)1 << round));                                        // h^(-2^r)
     const uint32_t* in = c->tail_vals.data();
-    uint32_t xinv = 1;
+    uint32_t xinv_m = to_mont(1);                         // Montgomery form, like the device tables: canonical * Montgomery = canonical
     for (size_t i = 0; i < half; ++i) {
         uint32_t u = in[i], v = in[i + half];
-        vals[i] = add(mulmod(add(u, v), inv2), mulmod(mulmod(sub(u, v), xinv), cc));
-        xinv = mulmod(xinv, step);
+        vals[i] = add(mont_mul(add(u, v), d->inv2_mont), mont_mul(mont_mul(sub(u, v), xinv_m), cc_m));
+        xinv_m = mont_mul(xinv_m, step_m);
     }
     for (size_t i = 0; i < half; ++i) host_sha_leaf(vals[i], nodes + 8 * (half - 1 + i));
     host_sha_reduce(nodes, log_out);
