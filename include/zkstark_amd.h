@@ -92,8 +92,8 @@ int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
  * tail_log = T >= H, FRI layers of <= 2^T values (polynomial.rs:385 fold + merkle.rs:14 tree) are
  * computed by the calling thread as well.  Everything the host built is copied into the device arrays
  * before the call returns, so zk_layer_read / zk_merkle_path see complete trees.  Default: (8, 9) when
- * the CPU has SHA extensions, else (0, 0) = all on the device; the stage-by-stage entry points and
- * the field hash always run on the device.  Results are identical for every setting. */
+ * the CPU has SHA extensions, else (0, 0) = all on the device.  zk_merkle_commit hands over its tree top
+ * in the same way; the field hash always runs on the device.  Results are identical for every setting. */
 int zk_ctx_set_host_levels(zk_ctx *ctx, uint32_t top_log, uint32_t tail_log);
 int zk_ctx_get_host_levels(const zk_ctx *ctx, uint32_t *top_log, uint32_t *tail_log);
 /* The HIP stream every stage is enqueued on (hipStream_t). */

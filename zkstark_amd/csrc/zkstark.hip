@@ -128,13 +128,13 @@ uint32_t top_of(const zk_ctx* c, uint32_t tree) {
 // What the commit launch of `tree` posts to the host.  host = true (one-call flows): the digests of depth
 // host_top instead of the root, and for the layer with 2^(host_tail+1) values the values too -- the host
 // folds on from there.
-MailArgs mail_of(zk_ctx* c, uint32_t tree, bool host) {
+MailArgs mail_of(zk_ctx* c, uint32_t tree, bool host, bool feed_tail = true) {
     MailArgs m;
     m.mailbox = c->d_mailbox;
     m.seq = ++c->mail_seq;
     m.counter = c->d_counter;
     m.top = host ? top_of(c, tree) : 0;
-    if (m.top && c->host_tail && tree >= 1 && layer_log(c, tree) == c->host_tail + 1) {
+    if (feed_tail && m.top && c->host_tail && tree >= 1 && layer_log(c, tree) == c->host_tail + 1) {
         m.dump_src = c->d_layers + c->layer_off[tree];
         m.dump_log = c->host_tail + 1;
         m.vals_off = (uint32_t)kMailValsOff;
@@ -145,10 +145,10 @@ MailArgs mail_of(zk_ctx* c, uint32_t tree, bool host) {
 }
 
 // Builds tree `layer`; the launch that reaches the hand-over depth posts its digests to the host mailbox.
-// host = false: the whole tree on the device (the stage-by-stage API).
-int do_merkle(zk_ctx* c, uint32_t layer, bool host = false) {
+// host = false: the whole tree on the device; feed_tail = false: a stand-alone commitment (stage-by-stage API).
+int do_merkle(zk_ctx* c, uint32_t layer, bool host = false, bool feed_tail = true) {
     HIPCHK(launch_merkle_build(c->d_layers + c->layer_off[layer], layer_log(c, layer), c->d_trees + c->tree_off[layer], c->stream,
-                               prof_of(c), mail_of(c, layer, host), c->hash));
+                               prof_of(c), mail_of(c, layer, host, feed_tail), c->hash));
     return ZK_OK;
 }
 
@@ -620,9 +620,11 @@ int zk_merkle_commit(zk_ctx* c, uint32_t layer, uint8_t root_out[32]) {
     if (!c || !root_out) return fail(ZK_ERR_INVALID, "zk_merkle_commit: null argument");
     if (layer > c->R + 1) return fail(ZK_ERR_INVALID, "zk_merkle_commit: layer %u out of range", layer);
     HIPCHK(hipSetDevice(c->device));
-    int rc = do_merkle(c, layer);
-    if (rc) return rc;
-    return read_root(c, layer, root_out);
+    begin_proof(c);                                      // a stand-alone commitment: nothing staged, no host-side FRI tail
+    int rc = do_merkle(c, layer, true, false);           // Merkle::new (merkle.rs:14); the last levels on this thread
+    if (!rc) rc = read_commit(c, layer, root_out);
+    if (!rc) rc = flush_host_parts(c);                   // the tree in HBM is complete before any later stage reads it
+    return rc;
 }
 
 int zk_compose(zk_ctx* c, const uint32_t alpha_raw[3]) {
