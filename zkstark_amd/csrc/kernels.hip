@@ -541,6 +541,9 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         }
         lds_store(&lvl[2 * i], d);
     }
+    // the layer values this workgroup produced are read by ANOTHER workgroup (the one that finishes last) when
+    // they are posted to the host: make every wave's stores visible device-wide, not only the posting wave's
+    if (LEAF && mail.dump_src) __threadfence();
     __syncthreads();
 #pragma unroll 1
     for (uint32_t t = 1; t <= j; ++t) {
