@@ -132,6 +132,12 @@ int zk_merkle_path(zk_ctx *ctx, uint32_t tree, size_t leaf, uint8_t *out, size_t
  * (channel.rs:34-36), i.e. the two fields of Proof (proof.rs:5-8). */
 int zk_prove_resident(zk_ctx *ctx, uint8_t *proof_out, size_t cap, size_t *proof_len,
                       uint8_t state_out[32]);
+/* zk_prove_resident on `count` (1..16) distinct contexts at once, one host thread each: the latency-bound
+ * phases of one proof overlap the hashing of the others on the same GPU.  Proof i goes to
+ * proofs_out + i*stride (stride >= the proof length), its length to lens_out[i], its state to
+ * states_out + 32*i. */
+int zk_prove_many(zk_ctx *const *ctxs, size_t count, uint8_t *proofs_out, size_t stride, size_t *lens_out,
+                  uint8_t *states_out);
 /* zk_trace_upload + zk_prove_resident. */
 int zk_prove(zk_ctx *ctx, const uint32_t *trace, size_t count, uint8_t *proof_out, size_t cap,
              size_t *proof_len, uint8_t state_out[32]);

@@ -445,6 +445,32 @@ def test_host_levels_argument_checks(zk):
     p.verify(strict=True)
 
 
+def test_prove_many_contexts_at_once(zk, orc):
+    """zk_prove_many: several contexts, one host thread each inside the library; every proof equals the
+    oracle's for its own trace, and a failing context is reported by index."""
+    sizes = [(12, 3, 99), (10, 3, 3141592), (15, 3, 7), (12, 3, 5)]
+    ctxs = [zk.Context(ln, lb) for ln, lb, _ in sizes]
+    try:
+        for c, (ln, lb, a1) in zip(ctxs, sizes):
+            c.trace_upload(zk.trace_fibsq((1 << ln) - 1, 1, a1))
+        for _ in range(3):
+            proofs = zk.prove_many(ctxs)
+            for p, (ln, lb, a1) in zip(proofs, sizes):
+                want = orc.prove(ln, lb, 1, a1, want_vectors=False)
+                assert p.data == want.proof and p.state == want.state
+        proofs[1].verify(strict=True)
+        bad = zk.trace_fibsq(4095, 1, 5)
+        bad[77] = (int(bad[77]) + 1) % P
+        ctxs[3].trace_upload(bad)
+        with pytest.raises(zk.ZkError, match="context 3"):
+            zk.prove_many(ctxs)
+        with pytest.raises(zk.ZkError):
+            zk.prove_many([ctxs[0], ctxs[0]])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 # ---- batched proving (SURVEY 8f item 4) ----------------------------------------------------------
 @pytest.mark.parametrize("log_n,log_b,log_batch", [(10, 3, 0), (10, 3, 1), (10, 3, 3), (6, 2, 4), (4, 1, 2), (2, 1, 3), (12, 3, 2),
                                                    (7, 4, 5), (5, 5, 1), (14, 2, 1), (9, 3, 6)])

@@ -77,6 +77,7 @@ SYMBOLS = {
     "zk_merkle_node": (_int, [_vp, _u32, _sz, _vp]),
     "zk_merkle_path": (_int, [_vp, _u32, _sz, _vp, C.POINTER(_sz)]),
     "zk_prove_resident": (_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "zk_prove_many": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "zk_prove": (_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
     "zk_verify": (_int, [_vp, _sz, _u32, _u32, _u32]),

@@ -709,6 +709,31 @@ int zk_prove(zk_ctx* c, const uint32_t* trace, size_t count, uint8_t* proof_out,
     return zk_prove_resident(c, proof_out, cap, proof_len, state_out);
 }
 
+// Several independent proofs in flight on one GPU: one host thread per context, so the latency-bound tree
+// tops of one proof overlap the hashing of the others (the device is VALU-saturated with three).
+int zk_prove_many(zk_ctx* const* ctxs, size_t count, uint8_t* proofs_out, size_t stride, size_t* lens_out, uint8_t* states_out) {
+    if (!ctxs || !proofs_out || !lens_out || !states_out || count == 0 || count > 16)
+        return fail(ZK_ERR_INVALID, "zk_prove_many: need 1..16 contexts and non-null outputs");
+    for (size_t i = 0; i < count; ++i) {
+        if (!ctxs[i]) return fail(ZK_ERR_INVALID, "zk_prove_many: context %zu is null", i);
+        for (size_t j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ZK_ERR_INVALID, "zk_prove_many: context %zu appears twice", i);
+    }
+    std::vector<int> rcs(count, ZK_OK);
+    std::vector<std::string> errs(count);
+    auto one = [&](size_t i) {
+        rcs[i] = zk_prove_resident(ctxs[i], proofs_out + i * stride, stride, &lens_out[i], states_out + 32 * i);
+        if (rcs[i]) errs[i] = last_error();              // the message lives in the worker's thread-local slot
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < count; ++i) th.emplace_back(one, i);
+    one(0);
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < count; ++i)
+        if (rcs[i]) return fail(rcs[i], "zk_prove_many: context %zu: %s", i, errs[i].c_str());
+    return ZK_OK;
+}
+
 int zk_last_transcript(const zk_ctx* c, zk_transcript_info* out) {
     if (!c || !out) return fail(ZK_ERR_INVALID, "zk_last_transcript: null argument");
     *out = c->info;

@@ -307,6 +307,24 @@ class Context:
         return info
 
 
+def prove_many(ctxs):
+    """Context.prove() (resident traces) on several contexts at once, one host thread each inside the
+    library (zk_prove_many): returns the proofs in order."""
+    ctxs = list(ctxs)
+    c0 = ctxs[0]
+    stride = max(_lib.load().zk_proof_data_len_queries(c.log_n, c.log_blowup, c.queries) for c in ctxs)
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    data = np.zeros((len(ctxs), stride), dtype=np.uint8)
+    lens = (C.c_size_t * len(ctxs))()
+    states = np.zeros((len(ctxs), 32), dtype=np.uint8)
+    check(_lib.load().zk_prove_many(handles, len(ctxs), data.ctypes.data_as(C.c_void_p), stride, lens, states.ctypes.data_as(C.c_void_p)))
+    out = []
+    for i, c in enumerate(ctxs):
+        out.append(Proof(states[i].tobytes(), data[i, :lens[i]].tobytes(), c.log_n, c.log_blowup, c.last_transcript().public_last,
+                         c.hash, c.queries))
+    return out
+
+
 class BatchContext:
     """2^log_batch proofs of one size in lockstep (zk_batch_*): every stage is one
     launch over the whole batch; each proof has its own channel and is byte-identical to Context.prove()."""
