@@ -63,6 +63,8 @@ extern "C" {
     pub fn zk_merkle_build_host(device: c_int, vals: *const u32, m: usize, nodes_out: *mut u8) -> c_int;
     // device-pointer primitives
     pub fn zk_dev_merkle_build(d_vals: *const u32, log_m: u32, d_nodes: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn zk_prove_many(ctxs: *const *mut zk_ctx, count: usize, proofs_out: *mut u8, stride: usize, lens_out: *mut usize,
+                         states_out: *mut u8) -> c_int;
     // settings of the one-call prover
     pub fn zk_ctx_set_queries(ctx: *mut zk_ctx, n_queries: u32) -> c_int;
     pub fn zk_ctx_set_hash(ctx: *mut zk_ctx, hash_kind: c_int) -> c_int;
