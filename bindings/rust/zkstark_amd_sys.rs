@@ -73,6 +73,8 @@ extern "C" {
     pub fn zk_batch_create(device: c_int, log_n: u32, log_blowup: u32, log_batch: u32, out: *mut *mut zk_batch) -> c_int;
     pub fn zk_batch_destroy(b: *mut zk_batch) -> c_int;
     pub fn zk_batch_size(b: *const zk_batch) -> usize;
+    pub fn zk_batch_set_queries(b: *mut zk_batch, n_queries: u32) -> c_int;
+    pub fn zk_batch_set_hash(b: *mut zk_batch, hash_kind: c_int) -> c_int;
     pub fn zk_batch_set_traces(b: *mut zk_batch, traces: *const u32) -> c_int;
     pub fn zk_batch_gen_fibsq(b: *mut zk_batch, a0: *const u32, a1: *const u32) -> c_int;
     pub fn zk_batch_public_last(b: *const zk_batch, out: *mut u32) -> c_int;

@@ -184,6 +184,9 @@ typedef struct zk_batch zk_batch;
 int zk_batch_create(int device, uint32_t log_n, uint32_t log_blowup, uint32_t log_batch, zk_batch **out);
 int zk_batch_destroy(zk_batch *b);
 size_t zk_batch_size(const zk_batch *b);                    /* 2^log_batch */
+/* As zk_ctx_set_queries (1..16 here) and zk_ctx_set_hash, for every proof of the batch. */
+int zk_batch_set_queries(zk_batch *b, uint32_t n_queries);
+int zk_batch_set_hash(zk_batch *b, int hash_kind);
 size_t zk_batch_device_bytes(const zk_batch *b);
 /* traces: [batch][n-1] canonical residues (prover.rs:32-39 per proof), uploaded and kept resident. */
 int zk_batch_set_traces(zk_batch *b, const uint32_t *traces);
@@ -192,7 +195,7 @@ int zk_batch_gen_fibsq(zk_batch *b, const uint32_t *a0, const uint32_t *a1);
 /* out[p] = a[n-2] of proof p: the public input its verifier needs (prover.rs:42, proof.rs:68). */
 int zk_batch_public_last(const zk_batch *b, uint32_t *out);
 /* proofs_out: [batch][stride] bytes, stride >= zk_proof_data_len(log_n, log_blowup); states_out:
- * [batch][32].  Fails with ZK_ERR_CHECK, naming the proof, if a trace breaks the constraints. */
+ * [batch][32] (with q queries: zk_proof_data_len_queries).  Fails with ZK_ERR_CHECK, naming the proof, if a trace breaks the constraints. */
 int zk_batch_prove(zk_batch *b, uint8_t *proofs_out, size_t stride, uint8_t *states_out);
 
 /* ---- proof: proof.rs ------------------------------------------------------- */

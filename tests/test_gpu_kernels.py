@@ -497,6 +497,27 @@ def test_batch_prover_matches_oracle(zk, orc, log_n, log_b, log_batch):
         proofs[p].verify()
 
 
+@pytest.mark.parametrize("hash_name,q", [("sha256", 3), ("field", 1), ("field", 2)])
+def test_batch_prover_queries_and_field_hash(zk, orc, hash_name, q):
+    """The batch honours the same settings as a context: q decommitment queries, field-native Merkle hash."""
+    log_n, log_b, log_batch = 8, 3, 2
+    a1s = [11 + p for p in range(1 << log_batch)]
+    with zk.BatchContext(log_n, log_b, log_batch, hash=hash_name, queries=q) as bc:
+        bc.gen_fibsq([1] * len(a1s), a1s)
+        proofs = bc.prove()
+    try:
+        orc.set_hash(1 if hash_name == "field" else 0)
+        orc.set_queries(q)
+        for p in (0, 3):
+            want = orc.prove(log_n, log_b, 1, a1s[p], want_vectors=False)
+            assert want.rc == 0 and proofs[p].data == want.proof and proofs[p].state == want.state
+    finally:
+        orc.set_hash(0)
+        orc.set_queries(1)
+    for pr in proofs:
+        pr.verify(strict=True)
+
+
 def test_batch_prover_host_traces_and_single_context(zk):
     """Traces handed over from the host; each proof equals Context.prove() of the same trace."""
     log_n, log_b, log_batch = 8, 3, 3

@@ -90,6 +90,8 @@ SYMBOLS = {
     "zk_batch_create": (_int, [_int, _u32, _u32, _u32, C.POINTER(_vp)]),
     "zk_batch_destroy": (_int, [_vp]),
     "zk_batch_size": (_sz, [_vp]),
+    "zk_batch_set_queries": (_int, [_vp, _u32]),
+    "zk_batch_set_hash": (_int, [_vp, _int]),
     "zk_batch_device_bytes": (_sz, [_vp]),
     "zk_batch_set_traces": (_int, [_vp, _vp]),
     "zk_batch_gen_fibsq": (_int, [_vp, _vp, _vp]),

@@ -122,7 +122,9 @@ struct zk_batch {
     uint64_t *d_goff = nullptr, *h_goff = nullptr;
     uint32_t *d_gout = nullptr, *h_gout = nullptr;
     uint32_t* h_last = nullptr;       // pinned: [batch][B] last layer / [batch] last trace values
-    size_t per_proof_vals = 0, per_proof_digs = 0;
+    size_t per_proof_vals = 0, per_proof_digs = 0;   // per query
+    uint32_t queries = 1;             // decommitment queries per proof (1 = the reference, prover.rs:263)
+    int hash = 0;                     // Merkle hash: 0 = SHA-256 (reference), 1 = field-native
     std::vector<uint32_t> first, last;
     bool have_traces = false;
     size_t device_bytes = 0;
@@ -142,6 +144,21 @@ MailArgs bmail(zk_batch* b) {
 // the batch's roots of the last commit launch: [batch][8] state words in the mailbox
 int bwait_roots(zk_batch* b) { return wait_flag(b->h_mail, b->mail_seq, b->stream); }
 const uint32_t* broot(const zk_batch* b, size_t proof) { return b->h_mail + kMailDigests + 8 * proof; }
+
+// gather buffers for q queries per proof (offsets in, values + digests out; device and pinned host copies)
+int balloc_gather(zk_batch* b, uint32_t q) {
+    for (void* p : {(void*)b->d_goff, (void*)b->d_gout}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)b->h_goff, (void*)b->h_gout}) if (p) (void)hipHostFree(p);
+    b->d_goff = nullptr; b->h_goff = nullptr; b->d_gout = nullptr; b->h_gout = nullptr;
+    const size_t slots = b->batch * q * (b->per_proof_vals + b->per_proof_digs);
+    const size_t out_words = b->batch * q * (b->per_proof_vals + 8 * b->per_proof_digs);
+    HIPCHK(hipMalloc((void**)&b->d_goff, slots * 8));
+    HIPCHK(hipMalloc((void**)&b->d_gout, out_words * 4));
+    HIPCHK(hipHostMalloc((void**)&b->h_goff, slots * 8));
+    HIPCHK(hipHostMalloc((void**)&b->h_gout, out_words * 4));
+    b->queries = q;
+    return ZK_OK;
+}
 
 int bchal_upload(zk_batch* b) {
     HIPCHK(hipMemcpyAsync(b->d_chal, b->h_chal, b->batch * sizeof(BatchChal), hipMemcpyHostToDevice, b->stream));
@@ -215,10 +232,7 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
     b->per_proof_vals = 4 + 2 * (size_t)b->R;
     b->per_proof_digs = 4 * (size_t)b->L;
     for (uint32_t i = 0; i < b->R; ++i) b->per_proof_digs += 2 * (size_t)(b->L - i);
-    const size_t slots = b->batch * (b->per_proof_vals + b->per_proof_digs);
-    if ((rc = dm(&b->d_goff, slots * 8)) || (rc = dm(&b->d_gout, b->batch * (b->per_proof_vals + 8 * b->per_proof_digs) * 4))) return bail(rc);
-    HIPCHK_B(hipHostMalloc((void**)&b->h_goff, slots * 8));
-    HIPCHK_B(hipHostMalloc((void**)&b->h_gout, b->batch * (b->per_proof_vals + 8 * b->per_proof_digs) * 4));
+    if ((rc = balloc_gather(b, 1))) return bail(rc);
     HIPCHK_B(hipHostMalloc((void**)&b->h_chal, b->batch * sizeof(BatchChal)));
     HIPCHK_B(hipHostMalloc((void**)&b->h_last, b->batch * (b->B > 2 ? b->B : 2) * 4));
     HIPCHK_B(hipHostMalloc((void**)&b->h_mail, kMailWords * 4, hipHostMallocMapped | hipHostMallocCoherent));
@@ -240,6 +254,19 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
 }
 
 size_t zk_batch_size(const zk_batch* b) { return b ? b->batch : 0; }
+int zk_batch_set_queries(zk_batch* b, uint32_t n_queries) {
+    if (!b) return fail(ZK_ERR_INVALID, "null batch");
+    if (n_queries < 1 || n_queries > 16) return fail(ZK_ERR_INVALID, "zk_batch_set_queries: need 1 <= n_queries <= 16");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return n_queries == b->queries ? (int)ZK_OK : balloc_gather(b, n_queries);
+}
+int zk_batch_set_hash(zk_batch* b, int hash_kind) {
+    if (!b) return fail(ZK_ERR_INVALID, "null batch");
+    if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_batch_set_hash: unknown hash %d", hash_kind);
+    b->hash = hash_kind;
+    return ZK_OK;
+}
 size_t zk_batch_device_bytes(const zk_batch* b) { return b ? b->device_bytes : 0; }
 
 // traces: [batch][n-1] canonical residues on the host (prover.rs:32-39 per proof)
@@ -282,7 +309,9 @@ int zk_batch_public_last(const zk_batch* b, uint32_t* out) {
 int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* states_out) {
     if (!b || !proofs_out || !states_out) return fail(ZK_ERR_INVALID, "zk_batch_prove: null argument");
     if (!b->have_traces) return fail(ZK_ERR_STATE, "zk_batch_prove: no traces");
-    const size_t plen = proof_data_len(b->log_n, b->log_b, 1);
+    const uint32_t Q = b->queries;
+    const int hash = b->hash;
+    const size_t plen = proof_data_len(b->log_n, b->log_b, Q);
     if (stride < plen) return fail(ZK_ERR_BUFFER, "zk_batch_prove: stride %zu < proof length %zu", stride, plen);
     HIPCHK(hipSetDevice(b->device));
     const size_t nb = b->batch, N = b->N, B = b->B;
@@ -302,7 +331,7 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
     auto wait_roots = [&]() { double t = now_us(); int r = bwait_roots(b); t_wait += now_us() - t; return r; };
     // f = LDE of every trace, committed (prover.rs:60-85)
     if ((rc = dom_lde(d, b->d_trace, b->d_coef, b->d_layers + b->layer_off[0], b->stream, nullptr, (uint32_t)nb))) return rc;
-    HIPCHK(launch_merkle_build(b->d_layers + b->layer_off[0], L + lb, b->d_trees + b->tree_off[0], b->stream, nullptr, bmail(b), 0));
+    HIPCHK(launch_merkle_build(b->d_layers + b->layer_off[0], L + lb, b->d_trees + b->tree_off[0], b->stream, nullptr, bmail(b), hash));
     // proof-independent part of the composition constants (compose_args with alpha = 1)
     ComposeBatchArgs ca;
     {
@@ -322,7 +351,7 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
         c.alpha0_mont = to_mont(a0); c.alpha1g2_mont = to_mont(mulmod(a1, g2)); c.alpha2_mont = to_mont(a2);
     });
     if ((rc = bchal_upload(b))) return rc;
-    HIPCHK(launch_compose_merkle_batch(ca, lb, b->d_trees + b->tree_off[1], b->stream, nullptr, bmail(b), 0));   // prover.rs:166-176
+    HIPCHK(launch_compose_merkle_batch(ca, lb, b->d_trees + b->tree_off[1], b->stream, nullptr, bmail(b), hash));   // prover.rs:166-176
     for (uint32_t r = 0; r <= R; ++r) {
         if ((rc = wait_roots())) return rc;
         if (r == R) {
@@ -341,7 +370,7 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
         FoldBatchArgs fa;
         if ((rc = fold_args(d, b->d_layers + b->layer_off[1 + r], b->d_layers + b->layer_off[2 + r], L - r, r, 0, fa.a))) return rc;
         fa.chal = b->d_chal;
-        HIPCHK(launch_fold_merkle_batch(fa, lb, b->d_trees + b->tree_off[2 + r], b->stream, nullptr, bmail(b), 0));   // prover.rs:201-214
+        HIPCHK(launch_fold_merkle_batch(fa, lb, b->d_trees + b->tree_off[2 + r], b->stream, nullptr, bmail(b), hash));   // prover.rs:201-214
     }
     lap("lde .. last roots");
     if (timing) fprintf(stderr, "[zk batch timing]   of which waiting for the device %.1f us\n", t_wait);
@@ -354,12 +383,13 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
                 return fail(ZK_ERR_CHECK, "proof %zu of the batch: last FRI layer is not constant (prover.rs:238): its trace does not satisfy the constraints", p);
     // queries and the offsets of every opening (prover.rs:263-289); node j of proof p's tree over m leaves
     // (depth dd, index i) is node 2^(lb+dd) - 1 + p 2^dd + i of the batch heap
-    const size_t nv = b->per_proof_vals, ndg = b->per_proof_digs;
+    const size_t nv = Q * b->per_proof_vals, ndg = Q * b->per_proof_digs;     // per proof, all its queries
     uint64_t* voff = b->h_goff;
     uint64_t* doff = b->h_goff + nb * nv;
     b->pool->run(nb, 16, [&](size_t p) {
         ch[p].commit_u32(b->h_last[p * B]);                               // prover.rs:254
-        const size_t x = (size_t)ch[p].get_u32() % (N - 2 * B);           // prover.rs:263
+        uint32_t qraw[kMaxQueries];
+        for (uint32_t k = 0; k < Q; ++k) qraw[k] = ch[p].get_u32();       // prover.rs:263 (x Q)
         uint64_t* vo = voff + p * nv;
         uint64_t* dofs = doff + p * ndg;
         std::vector<size_t> nodes;
@@ -373,14 +403,17 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
                 --dd;
             }
         };
-        *vo++ = b->layer_off[0] + p * N + x;         add_path(0, L, x);
-        *vo++ = b->layer_off[0] + p * N + x + B;     add_path(0, L, x + B);
-        *vo++ = b->layer_off[0] + p * N + x + 2 * B; add_path(0, L, x + 2 * B);
-        *vo++ = b->layer_off[1] + p * N + x;         add_path(1, L, x);
-        for (uint32_t i = 0; i < R; ++i) {
-            size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
-            *vo++ = b->layer_off[1 + i] + p * len + xi; add_path(1 + i, L - i, xi);
-            *vo++ = b->layer_off[1 + i] + p * len + nx; add_path(1 + i, L - i, nx);
+        for (uint32_t k = 0; k < Q; ++k) {
+            const size_t x = (size_t)qraw[k] % (N - 2 * B);
+            *vo++ = b->layer_off[0] + p * N + x;         add_path(0, L, x);
+            *vo++ = b->layer_off[0] + p * N + x + B;     add_path(0, L, x + B);
+            *vo++ = b->layer_off[0] + p * N + x + 2 * B; add_path(0, L, x + 2 * B);
+            *vo++ = b->layer_off[1] + p * N + x;         add_path(1, L, x);
+            for (uint32_t i = 0; i < R; ++i) {
+                size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
+                *vo++ = b->layer_off[1 + i] + p * len + xi; add_path(1 + i, L - i, xi);
+                *vo++ = b->layer_off[1 + i] + p * len + nx; add_path(1 + i, L - i, nx);
+            }
         }
     });
     lap("queries + opening offsets");
@@ -398,11 +431,13 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
         std::vector<uint8_t> dig(ndg * 32);
         for (size_t i = 0; i < ndg; ++i) digest_words_to_bytes(dw + 8 * i, dig.data() + 32 * i);
         size_t dpos = 0;
-        for (int k = 0; k < 4; ++k) { ch[p].commit_val_path(vals[k], dig.data() + 32 * dpos, L); dpos += L; }   // prover.rs:274-277
-        for (uint32_t i = 0; i < R; ++i) {                                                                       // prover.rs:280-289
-            size_t pl = L - i;
-            ch[p].commit_pair_paths(vals[4 + 2 * i], vals[5 + 2 * i], dig.data() + 32 * dpos, dig.data() + 32 * (dpos + pl), pl);
-            dpos += 2 * pl;
+        for (uint32_t q = 0; q < Q; ++q, vals += 4 + 2 * R) {
+            for (int k = 0; k < 4; ++k) { ch[p].commit_val_path(vals[k], dig.data() + 32 * dpos, L); dpos += L; }   // prover.rs:274-277
+            for (uint32_t i = 0; i < R; ++i) {                                                                       // prover.rs:280-289
+                size_t pl = L - i;
+                ch[p].commit_pair_paths(vals[4 + 2 * i], vals[5 + 2 * i], dig.data() + 32 * dpos, dig.data() + 32 * (dpos + pl), pl);
+                dpos += 2 * pl;
+            }
         }
         if (ch[p].data.size() != plen) { bad.store(1); return; }
         memcpy(proofs_out + p * stride, ch[p].data.data(), plen);          // channel.rs:34-36

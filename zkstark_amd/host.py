@@ -329,11 +329,15 @@ class BatchContext:
     """2^log_batch proofs of one size in lockstep (zk_batch_*): every stage is one
     launch over the whole batch; each proof has its own channel and is byte-identical to Context.prove()."""
 
-    def __init__(self, log_n=10, log_blowup=3, log_batch=4, device=0):
-        self.log_n, self.log_blowup, self.log_batch = log_n, log_blowup, log_batch
+    def __init__(self, log_n=10, log_blowup=3, log_batch=4, device=0, hash="sha256", queries=1):
+        self.log_n, self.log_blowup, self.log_batch, self.hash, self.queries = log_n, log_blowup, log_batch, hash, queries
         self.n, self.batch = 1 << log_n, 1 << log_batch
         self._h = C.c_void_p()
         check(_lib.load().zk_batch_create(device, log_n, log_blowup, log_batch, C.byref(self._h)))
+        if hash != "sha256":
+            check(_lib.load().zk_batch_set_hash(self._h, HASHES[hash]))
+        if queries != 1:
+            check(_lib.load().zk_batch_set_queries(self._h, queries))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -369,7 +373,7 @@ class BatchContext:
 
     def prove_raw(self):
         """Returns (proof bytes [batch][len] as a uint8 array, states [batch][32])."""
-        plen = _lib.load().zk_proof_data_len(self.log_n, self.log_blowup)
+        plen = _lib.load().zk_proof_data_len_queries(self.log_n, self.log_blowup, self.queries)
         data = np.zeros((self.batch, plen), dtype=np.uint8)
         states = np.zeros((self.batch, 32), dtype=np.uint8)
         check(_lib.load().zk_batch_prove(self._h, data.ctypes.data_as(C.c_void_p), plen, states.ctypes.data_as(C.c_void_p)))
@@ -378,7 +382,8 @@ class BatchContext:
     def prove(self):
         data, states = self.prove_raw()
         last = self.public_last()
-        return [Proof(states[p].tobytes(), data[p].tobytes(), self.log_n, self.log_blowup, int(last[p])) for p in range(self.batch)]
+        return [Proof(states[p].tobytes(), data[p].tobytes(), self.log_n, self.log_blowup, int(last[p]), self.hash, self.queries)
+                for p in range(self.batch)]
 
 
 def generate_proof(channel, log_n=10, log_blowup=3, a0=1, a1=3141592, ctx=None):
