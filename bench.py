@@ -121,6 +121,9 @@ def main():
     if world > 1 or force_sharded:
         from zkstark_amd import sharded
         if world == 1:
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         result = sharded.bench(args, rank, local_rank, world, barrier, staged=staged, force=force_sharded)
         log_n = result["log_n"]
