@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_sha.hpp"
 #include "internal.hpp"
 #include "sha256.hpp"
 #include "transcript.hpp"
@@ -129,6 +130,16 @@ struct zk_batch {
     bool have_traces = false;
     size_t device_bytes = 0;
     Pool* pool = nullptr;
+    // small batches: the device stops each tree `extra` levels above the per-proof roots and the host threads
+    // hash those levels (host_sha.hpp); staged level-major like the batch heap, copied back by scatter_kernel
+    bool host_levels = false;
+    uint32_t* h_stage = nullptr;      // pinned, mapped
+    uint32_t* d_stage = nullptr;
+    size_t stage_words = 0, stage_used = 0;
+    ScatterSeg* h_segs = nullptr;
+    ScatterSeg* d_segs = nullptr;
+    uint32_t n_segs = 0;
+    double seg_words = 0;
 };
 
 namespace {
@@ -136,14 +147,50 @@ namespace {
 size_t blayer_size(const zk_batch* b, uint32_t layer) { return layer == 0 ? b->N : (b->N >> (layer - 1)); }
 uint32_t blayer_log(const zk_batch* b, uint32_t layer) { return layer == 0 ? b->L : b->L - (layer - 1); }
 
-MailArgs bmail(zk_batch* b) {
+// Levels of each proof's tree (over 2^log_m leaves) that the host hashes: as many as the mailbox holds
+// (2^kMaxHostLog digests for the whole batch), none for the field hash or without SHA extensions.
+uint32_t bextra(const zk_batch* b, uint32_t log_m) {
+    if (!b->host_levels || b->hash != 0 || b->lb >= kMaxHostLog || log_m < 2) return 0;
+    uint32_t h = kMaxHostLog - b->lb;
+    if (h > log_m - 1) h = log_m - 1;
+    return h >= 3 ? h : 0;                               // two levels are not worth a hand-over
+}
+MailArgs bmail(zk_batch* b, uint32_t log_m) {
     MailArgs m;
-    m.mailbox = b->d_mail; m.seq = ++b->mail_seq; m.counter = b->d_counter; m.top = b->lb;
+    m.mailbox = b->d_mail; m.seq = ++b->mail_seq; m.counter = b->d_counter; m.top = b->lb + bextra(b, log_m);
     return m;
 }
 // the batch's roots of the last commit launch: [batch][8] state words in the mailbox
 int bwait_roots(zk_batch* b) { return wait_flag(b->h_mail, b->mail_seq, b->stream); }
-const uint32_t* broot(const zk_batch* b, size_t proof) { return b->h_mail + kMailDigests + 8 * proof; }
+// After bwait_roots: hashes the `extra` host levels of every proof's tree `tree` and returns where the roots
+// are ([batch][8] state words): the mailbox itself when the device went all the way.
+const uint32_t* bfinish_roots(zk_batch* b, uint32_t tree, uint32_t log_m) {
+    const uint32_t h = bextra(b, log_m);
+    const uint32_t* posted = b->h_mail + kMailDigests;
+    if (!h) return posted;
+    const size_t nb = b->batch;
+    // stage[d], d < h: [proof][2^d] digests = level lb + d of the batch heap
+    std::vector<uint32_t*> lvl(h + 1);
+    for (uint32_t dd = 0; dd < h; ++dd) {
+        lvl[dd] = b->h_stage + b->stage_used;
+        b->stage_used += (nb << dd) * 8;
+    }
+    lvl[h] = const_cast<uint32_t*>(posted);
+    b->pool->run(nb, 1, [&](size_t p) {
+        for (uint32_t dd = h; dd-- > 0;) {
+            const uint32_t* child = lvl[dd + 1] + ((p << (dd + 1)) * 8);
+            uint32_t* out = lvl[dd] + ((p << dd) * 8);
+            for (size_t i = 0; i < ((size_t)1 << dd); ++i) host_sha_inner(child + 16 * i, child + 16 * i + 8, out + 8 * i);
+        }
+    });
+    for (uint32_t dd = 0; dd < h; ++dd) {
+        b->h_segs[b->n_segs++] = ScatterSeg{(uint64_t)(lvl[dd] - b->h_stage),
+                                            (uint64_t)b->tree_off[tree] + ((((uint64_t)1 << (b->lb + dd)) - 1) * 8),
+                                            (uint32_t)((nb << dd) * 8), 0};
+        b->seg_words += (double)((nb << dd) * 8);
+    }
+    return lvl[0];
+}
 
 // gather buffers for q queries per proof (offsets in, values + digests out; device and pinned host copies)
 int balloc_gather(zk_batch* b, uint32_t q) {
@@ -177,7 +224,7 @@ int zk_batch_destroy(zk_batch* b) {
     for (void* p : {(void*)b->d_trace, (void*)b->d_coef, (void*)b->d_layers, (void*)b->d_trees, (void*)b->d_seed, (void*)b->d_chal,
                     (void*)b->d_counter, (void*)b->d_goff, (void*)b->d_gout})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)b->h_chal, (void*)b->h_mail, (void*)b->h_goff, (void*)b->h_gout, (void*)b->h_last})
+    for (void* p : {(void*)b->h_chal, (void*)b->h_mail, (void*)b->h_goff, (void*)b->h_gout, (void*)b->h_last, (void*)b->h_stage})
         if (p) (void)hipHostFree(p);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b->pool;
@@ -239,6 +286,13 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
     memset(b->h_mail, 0, kMailWords * 4);
     memset(b->h_chal, 0, b->batch * sizeof(BatchChal));
     HIPCHK_B(hipHostGetDevicePointer((void**)&b->d_mail, b->h_mail, 0));
+    b->stage_words = (size_t)(b->R + 2) * ((size_t)8 << kMaxHostLog);
+    const size_t seg_bytes = (size_t)(b->R + 2) * kMaxHostLog * sizeof(ScatterSeg);
+    HIPCHK_B(hipHostMalloc((void**)&b->h_stage, b->stage_words * 4 + seg_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_B(hipHostGetDevicePointer((void**)&b->d_stage, b->h_stage, 0));
+    b->h_segs = reinterpret_cast<ScatterSeg*>(b->h_stage + b->stage_words);
+    b->d_segs = reinterpret_cast<ScatterSeg*>(b->d_stage + b->stage_words);
+    b->host_levels = host_sha_available() && !(getenv("ZK_HOST_TOP_LOG") && atoi(getenv("ZK_HOST_TOP_LOG")) == 0);
     HIPCHK_B(hipStreamSynchronize(b->stream));
 #undef HIPCHK_B
     b->first.assign(b->batch, 0);
@@ -246,7 +300,7 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
     unsigned hw = std::thread::hardware_concurrency();
     unsigned want = hw > 1 ? (hw - 1 < 15 ? hw - 1 : 15) : 0;
     if (const char* e = getenv("ZK_BATCH_THREADS")) want = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) - 1 : 0;
-    if (b->batch < 8) want = 0;
+    if (b->batch < 2) want = 0;
     b->pool = new (std::nothrow) Pool(want);
     if (!b->pool) return bail(fail(ZK_ERR_NOMEM, "out of host memory"));
     *out = b;
@@ -331,7 +385,8 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
     auto wait_roots = [&]() { double t = now_us(); int r = bwait_roots(b); t_wait += now_us() - t; return r; };
     // f = LDE of every trace, committed (prover.rs:60-85)
     if ((rc = dom_lde(d, b->d_trace, b->d_coef, b->d_layers + b->layer_off[0], b->stream, nullptr, (uint32_t)nb))) return rc;
-    HIPCHK(launch_merkle_build(b->d_layers + b->layer_off[0], L + lb, b->d_trees + b->tree_off[0], b->stream, nullptr, bmail(b), hash));
+    b->stage_used = 0; b->n_segs = 0; b->seg_words = 0;
+    HIPCHK(launch_merkle_build(b->d_layers + b->layer_off[0], L + lb, b->d_trees + b->tree_off[0], b->stream, nullptr, bmail(b, L), hash));
     // proof-independent part of the composition constants (compose_args with alpha = 1)
     ComposeBatchArgs ca;
     {
@@ -341,9 +396,10 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
     }
     const uint32_t g2 = mulmod(d->g, d->g);
     if ((rc = wait_roots())) return rc;
+    const uint32_t* roots = bfinish_roots(b, 0, L);
     b->pool->run(nb, 16, [&](size_t p) {
         uint8_t root[32];
-        digest_words_to_bytes(broot(b, p), root);
+        digest_words_to_bytes(roots + 8 * p, root);
         ch[p].commit_hash(root);                                          // prover.rs:85
         uint32_t a0 = ch[p].get_u32() % P, a1 = ch[p].get_u32() % P, a2 = ch[p].get_u32() % P;   // prover.rs:163-165
         BatchChal& c = b->h_chal[p];
@@ -351,17 +407,18 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
         c.alpha0_mont = to_mont(a0); c.alpha1g2_mont = to_mont(mulmod(a1, g2)); c.alpha2_mont = to_mont(a2);
     });
     if ((rc = bchal_upload(b))) return rc;
-    HIPCHK(launch_compose_merkle_batch(ca, lb, b->d_trees + b->tree_off[1], b->stream, nullptr, bmail(b), hash));   // prover.rs:166-176
+    HIPCHK(launch_compose_merkle_batch(ca, lb, b->d_trees + b->tree_off[1], b->stream, nullptr, bmail(b, L), hash));   // prover.rs:166-176
     for (uint32_t r = 0; r <= R; ++r) {
         if ((rc = wait_roots())) return rc;
+        roots = bfinish_roots(b, 1 + r, L - r);                           // tree 1 + r: 2^(L - r) leaves per proof
         if (r == R) {
-            b->pool->run(nb, 32, [&](size_t p) { uint8_t root[32]; digest_words_to_bytes(broot(b, p), root); ch[p].commit_hash(root); });
+            b->pool->run(nb, 32, [&](size_t p) { uint8_t root[32]; digest_words_to_bytes(roots + 8 * p, root); ch[p].commit_hash(root); });
             break;
         }
         const uint32_t winv_half = mulmod(invmod(powmod(d->shift, (uint64_t)1 << r)), invmod(2));
         b->pool->run(nb, 32, [&](size_t p) {
             uint8_t root[32];
-            digest_words_to_bytes(broot(b, p), root);
+            digest_words_to_bytes(roots + 8 * p, root);
             ch[p].commit_hash(root);                                      // prover.rs:180 / :224
             uint32_t beta = ch[p].get_u32() % P;                          // prover.rs:200
             b->h_chal[p].c_mont = to_mont(mulmod(beta, winv_half));
@@ -370,7 +427,7 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
         FoldBatchArgs fa;
         if ((rc = fold_args(d, b->d_layers + b->layer_off[1 + r], b->d_layers + b->layer_off[2 + r], L - r, r, 0, fa.a))) return rc;
         fa.chal = b->d_chal;
-        HIPCHK(launch_fold_merkle_batch(fa, lb, b->d_trees + b->tree_off[2 + r], b->stream, nullptr, bmail(b), hash));   // prover.rs:201-214
+        HIPCHK(launch_fold_merkle_batch(fa, lb, b->d_trees + b->tree_off[2 + r], b->stream, nullptr, bmail(b, L - r - 1), hash));   // prover.rs:201-214
     }
     lap("lde .. last roots");
     if (timing) fprintf(stderr, "[zk batch timing]   of which waiting for the device %.1f us\n", t_wait);
@@ -419,6 +476,7 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
     lap("queries + opening offsets");
     const size_t tv = nb * nv, td = nb * ndg;
     HIPCHK(hipMemcpyAsync(b->d_goff, b->h_goff, (tv + td) * 8, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(launch_scatter(b->d_stage, b->d_segs, b->n_segs, b->seg_words, b->d_trees, nullptr, b->stream, nullptr));   // host-built levels
     HIPCHK(launch_gather(b->d_layers, b->d_goff, (uint32_t)tv, 1, b->d_gout, b->stream, nullptr));
     HIPCHK(launch_gather(b->d_trees, b->d_goff + tv, (uint32_t)td, 8, b->d_gout + tv, b->stream, nullptr));
     HIPCHK(hipMemcpyAsync(b->h_gout, b->d_gout, (tv + td * 8) * 4, hipMemcpyDeviceToHost, b->stream));
