@@ -518,9 +518,9 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
     p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
 }
 
-// When the launch produces the root (depth_in == j) and a mailbox is given, the root is also
-// written to host-mapped memory followed by a sequence number, so the host prover can poll for
-// it instead of paying a blit kernel + stream synchronisation per commitment.
+// When the launch reaches the hand-over depth (MailArgs.top; 0 = the root) and a mailbox is given, the
+// digests of that depth are also written to host-mapped memory followed by a sequence number, so the
+// host prover can poll for them instead of paying a blit kernel + stream synchronisation per commitment.
 template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t j,
                                                                MailArgs mail, size_t off) {
@@ -732,8 +732,8 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
         depth -= k;
     }
     if (throughput_only) return hipGetLastError();
-    // top > 0 (whole trees only): the build ends at depth `top`, whose 2^top digests go to the mailbox slots
-    // and are finished by the host (host_sha.hpp)
+    // top > 0 (whole trees only): the build ends at depth `top`, whose 2^top digests go to the mailbox and the
+    // levels above are hashed by the host (host_sha.hpp; batches: those digests are the per-proof roots)
     MailArgs mail = mail_in;
     if (stop != 0 || mail.top >= log_m) mail.top = 0;
     const uint32_t end = stop == 0 ? mail.top : stop;
