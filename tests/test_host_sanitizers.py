@@ -32,3 +32,15 @@ def test_verifier_memory_safety(orc, checker, tmp_path, log_n, log_b, hash_kind)
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ok: valid accepted" in out.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_batch_pool_under_sanitizers(tmp_path, san):
+    """The fork-join pool of the batched prover (csrc/pool.hpp): lock-free job hand-off with spinning and blocking
+    workers, run under ThreadSanitizer and ASan/UBSan."""
+    exe = str(tmp_path / "pool_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", f"-fsanitize={san}", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "pool_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "pool ok" in out.stdout

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzkstark_amd.so")
 SOURCES = ["kernels.hip", "ntt_fast.hip", "domain.hip", "zkstark.hip", "batch.hip", "host_sha.cpp"]
-HEADERS = ["field.hpp", "sha256.hpp", "fieldhash.hpp", "kernels.hpp", "transcript.hpp", "host_sha.hpp", "internal.hpp", os.path.join("..", "..", "include", "zkstark_amd.h")]
+HEADERS = ["field.hpp", "sha256.hpp", "fieldhash.hpp", "kernels.hpp", "transcript.hpp", "host_sha.hpp", "internal.hpp", "pool.hpp", os.path.join("..", "..", "include", "zkstark_amd.h")]
 ARCH = "gfx950"
 
 
