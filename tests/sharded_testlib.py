@@ -106,3 +106,32 @@ class OracleBackend:
 
     def sync(self):
         pass
+
+
+class ChunkingOracleBackend(OracleBackend):
+    """Adds the chunked commitment of HipBackend (merkle_chunk / merkle_finish), so that the chunked exchange of
+    zkstark_amd.sharded runs with real multi-rank collectives on CPU."""
+
+    def merkle_chunk(self, recv, log_parts, log_cnt, nodes, log_m, chunk):
+        import hashlib  # noqa: F401
+        self.calls["merkle_chunk"] = self.calls.get("merkle_chunk", 0) + 1
+        parts, cnt = 1 << log_parts, 1 << log_cnt
+        log_s = log_parts + log_cnt
+        leaves = self._np(recv)[:parts * cnt].reshape(parts, cnt).T.reshape(-1)      # leaf u*parts + q = recv[q][u]
+        sub = _w2(oracle.merkle_build(np.ascontiguousarray(leaves))).reshape(-1, 8)    # heap of the chunk alone
+        heap = self._np(nodes)
+        top = log_m - log_s                                                           # depth of the chunk root in the block tree
+        for d in range(log_s + 1):
+            src = sub[(1 << d) - 1:(2 << d) - 1]
+            first = (1 << (top + d)) - 1 + (chunk << d)
+            heap[first * 8:(first + (1 << d)) * 8] = src.reshape(-1)
+
+    def merkle_finish(self, nodes, log_m, log_chunks):
+        import hashlib
+        self.calls["merkle_finish"] = self.calls.get("merkle_finish", 0) + 1
+        heap = self._np(nodes)
+        for d in range(log_chunks - 1, -1, -1):
+            for i in range(1 << d):
+                j = (1 << d) - 1 + i
+                kids = heap[(2 * j + 1) * 8:(2 * j + 3) * 8].astype(">u4").tobytes()
+                heap[j * 8:(j + 1) * 8] = np.frombuffer(hashlib.sha256(kids).digest(), dtype=">u4").astype(np.uint32)

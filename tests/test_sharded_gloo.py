@@ -97,6 +97,48 @@ def test_sharded_layer_size_threshold(orc, world, log_n, log_b, min_chunk_log, m
         assert data == want.proof and state == want.state, f"rank {rank}"
 
 
+def _chunk_worker(rank, world, port, log_n, log_b, lists, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from sharded_testlib import ChunkingOracleBackend
+        from zkstark_amd import sharded
+        be = ChunkingOracleBackend()
+        sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(lists=lists), be, min_chunk_log=3, overlap_min_log=3)
+        sp.trace_upload(oracle.trace_fibsq((1 << log_n) - 1))
+        proof = sp.prove()
+        q.put((rank, proof.data, proof.state, be.calls.get("merkle_chunk", 0), be.calls.get("merkle_finish", 0)))
+        sp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,log_b,lists", [(2, 8, 3, True), (4, 10, 2, True), (8, 11, 3, True), (2, 8, 3, False), (4, 10, 2, False)])
+def test_chunked_exchange_multirank(orc, world, log_n, log_b, lists):
+    """The chunked commitment of the N > 1 path with real collectives between CPU ranks: hashing chunk c while
+    chunk c+1 is exchanged, either as list exchanges over slices of the layer (what RCCL runs; emulated with
+    send/recv pairs on gloo) or packed.  Every rank must produce the oracle's proof."""
+    want = orc.prove(log_n, log_b, want_vectors=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, log_n, log_b, lists, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, data, state, n_chunk, n_finish in out:
+        assert n_chunk >= 8 and n_finish >= 2 * 1, "the test must go through the chunked path"
+        assert data == want.proof and state == want.state, f"rank {rank}"
+
+
 def test_sharded_requires_world_dividing_blowup(zk):
     from zkstark_amd import sharded
 

@@ -77,13 +77,23 @@ def words_to_bytes(words):
     return np.ascontiguousarray(words, dtype=np.uint32).astype(">u4").tobytes()
 
 
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class Comm:
     """The three collectives the path needs, over torch.distributed.  `staged` moves device tensors
     through host memory (gloo); with the nccl backend (RCCL) tensors are exchanged in place."""
 
-    def __init__(self, group=None, staged=False, force=False):
+    def __init__(self, group=None, staged=False, force=False, lists=None):
         import torch.distributed as dist
         self.dist, self.group, self.staged = dist, group, staged
+        self.lists = lists          # None: list exchanges only where the backend has them (RCCL); True: emulate with send/recv pairs
         self.force = force          # run the collectives even with one rank (exercises RCCL on a one-GPU box)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -107,12 +117,24 @@ class Comm:
         return self.dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
     def lists_ok(self):
-        """True when the backend exchanges lists of (non-contiguous) slices in place: RCCL does, gloo does not."""
+        """True when the backend exchanges lists of (non-contiguous) slices in place: RCCL does; gloo does not
+        (there the caller packs and uses all_to_all, unless lists=True asks for the send/recv emulation)."""
+        if self.lists is not None:
+            return bool(self.lists) and not self.staged
         return not self.staged and self.dist.get_backend(self.group) == "nccl"
 
     def all_to_all_list_async(self, sends, recvs):
         """sends[p] goes to rank p, recvs[q] comes from rank q (any slices of device tensors, no packing)."""
-        return self.dist.all_to_all(recvs, sends, group=self.group, async_op=True)
+        if self.dist.get_backend(self.group) == "nccl":
+            return self.dist.all_to_all(recvs, sends, group=self.group, async_op=True)
+        works = []                                       # backends without alltoall: pairwise, FIFO per pair
+        for q in range(self.world):
+            if q == self.rank:
+                recvs[q].copy_(sends[q])
+            else:
+                works.append(self.dist.irecv(recvs[q], src=q, group=self.group))
+                works.append(self.dist.isend(sends[q], dst=q, group=self.group))
+        return _Works(works)
 
     def all_gather(self, t, out):
         """out: [world * len(t)] flat."""
