@@ -266,7 +266,10 @@ int zk_lde_host(int device, const uint32_t *trace, uint32_t log_n, uint32_t log_
  * zkstark_amd/sharded.py drives these between RCCL collectives).  A domain is
  * {shift * h^i, i < 2^(log_n+log_blowup)}, h = zk_field_root_of_unity(log_n+log_blowup), with
  * the tables the kernels need; the reference's domain is shift = 5 (prover.rs:69).  log_blowup
- * may be 0.  fold_only != 0 builds only what zk_dev_fri_fold needs. */
+ * may be 0.  fold_only != 0 builds only what zk_dev_fri_fold needs.  Entry points that take only device
+ * pointers and a stream (zk_dev_merkle_build*, zk_dev_interleave, zk_dev_gather, ...) launch on the
+ * calling thread's current device: select the device the buffers live on first (hipSetDevice /
+ * torch.cuda.set_device), as one process per GPU does once at start-up. */
 typedef struct zk_dom zk_dom;
 int zk_dom_create(int device, uint32_t log_n, uint32_t log_blowup, uint32_t shift, int fold_only, zk_dom **out);
 int zk_dom_destroy(zk_dom *dom);

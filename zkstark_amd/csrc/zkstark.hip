@@ -539,6 +539,7 @@ size_t zk_ctx_device_bytes(const zk_ctx* c) { return c ? c->device_bytes : 0; }
 void* zk_ctx_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int zk_ctx_sync(zk_ctx* c) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
@@ -925,17 +926,20 @@ int zk_dom_destroy(zk_dom* d) {
 int zk_dev_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t* d_out, void* stream) {
     if (!d || !d_trace || !d_coef || !d_out) return fail(ZK_ERR_INVALID, "zk_dev_lde: null argument");
     if (!d->d_inv_xm1) return fail(ZK_ERR_STATE, "zk_dev_lde: fold-only domain");
+    HIPCHK(hipSetDevice(d->device));
     return dom_lde(d, d_trace, d_coef, d_out, (hipStream_t)stream, dev_prof());
 }
 int zk_dev_compose(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t first, uint32_t last,
                    const uint32_t alpha_raw[3], void* stream) {
     if (!d || !d_f || !d_cp || !alpha_raw) return fail(ZK_ERR_INVALID, "zk_dev_compose: null argument");
     if (!d->d_inv_xm1) return fail(ZK_ERR_STATE, "zk_dev_compose: fold-only domain");
+    HIPCHK(hipSetDevice(d->device));
     return dom_compose(d, d_f, d_cp, first, last, alpha_raw, (hipStream_t)stream, dev_prof());
 }
 int zk_dev_fri_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round,
                     uint32_t beta_raw, void* stream) {
     if (!d || !d_in || !d_out) return fail(ZK_ERR_INVALID, "zk_dev_fri_fold: null argument");
+    HIPCHK(hipSetDevice(d->device));
     return dom_fold(d, d_in, d_out, log_m, round, beta_raw, (hipStream_t)stream, dev_prof());
 }
 int zk_dev_trace_fibsq_batch(const uint32_t* d_a0, const uint32_t* d_a1, uint32_t batch, uint32_t count, uint32_t* d_out, void* stream) {
