@@ -276,8 +276,8 @@ def main():
         }
         if "pipelined" in result:
             out["pipelined"] = result["pipelined"]
-        for k in ("lde_commit_2e20", "reference_size_2e13", "batched_2e13"):
-            if k in result:
+        for k in ("lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded"):
+            if result.get(k) is not None:
                 out[k] = result[k]
         if world == 1 and not args.no_cpu_baseline and args.hash == "sha256":
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)

@@ -752,7 +752,19 @@ def bench(args, rank, local_rank, world, barrier, staged=False, force=False):
     per_kernel = stats()
     lib.zk_dev_set_profiling(0)
     N = 1 << (log_n + args.log_blowup)
-    res = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": setup_ms, "device_bytes": 0,
+    # secondary figure, BASELINE.json configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit only
+    lde_commit = None
+    if not getattr(args, "no_secondary", False):
+        root0 = sp.lde_commit()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            root1 = sp.lde_commit()
+        barrier()
+        dtl = (time.perf_counter() - t0) / 5
+        lde_commit = {"workload": f"configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit, domain 2^{log_n + args.log_blowup} over {world} GPUs",
+                      "ms": dtl * 1e3, "value": N / dtl, "unit": "field-elements/s", "root_stable": root0 == root1}
+    res = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": setup_ms, "device_bytes": 0, "lde_commit_sharded": lde_commit,
            "proof_bytes": len(proof.data), "scaling": "weak", "units": N * args.steps,
            "parallelism": f"one proof sharded over {world} GPUs (cyclic domain, all-to-all per commitment)" +
                           (", plain collectives only" if conservative else ""),
