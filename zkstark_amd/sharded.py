@@ -721,7 +721,8 @@ def bench(args, rank, local_rank, world, barrier, staged=False, force=False):
         # the optional accelerations (chunked list exchange, shared-memory root board) are the only parts that
         # cannot be rehearsed with RCCL on a one-GPU box: fall back to the plain collectives rather than fail
         if rank == 0:
-            print(f"[bench] sharded prover failed with the optional accelerations ({e}); retrying without them", flush=True)
+            import sys
+            print(f"[bench] sharded prover failed with the optional accelerations ({e}); retrying without them", file=sys.stderr, flush=True)
         sp.close()
         be = HipBackend(local_rank)
         sp = ShardedProver(log_n, args.log_blowup, comm, be, overlap_min_log=99, use_board=False)
