@@ -91,6 +91,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # stdout carries exactly one JSON line: native libraries (RCCL prints a banner when a communicator is
+    # created) write to file descriptor 1 directly, so it is pointed at stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import zkstark_amd as zk
@@ -281,7 +287,8 @@ def main():
                 out[k] = result[k]
         if world == 1 and not args.no_cpu_baseline and args.hash == "sha256":
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_sharded:
         dist.destroy_process_group()
 
