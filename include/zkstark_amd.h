@@ -57,6 +57,9 @@ enum zk_hash_kind { ZK_HASH_SHA256 = 0, ZK_HASH_FIELD = 1 };
 
 const char *zk_last_error(void);
 const char *zk_version(void);
+/* Hash of the sources and headers the library was built from (zkstark_amd/build.py: source_hash()); loaders
+ * compare it with the tree to refuse a stale binary. */
+const char *zk_build_hash(void);
 
 /* ---- scalar field helpers on the host: field.rs:8-211 ------------------- */
 uint32_t zk_field_add(uint32_t a, uint32_t b);       /* field.rs:99-111 */
@@ -132,6 +135,12 @@ int zk_merkle_path(zk_ctx *ctx, uint32_t tree, size_t leaf, uint8_t *out, size_t
  * (channel.rs:34-36), i.e. the two fields of Proof (proof.rs:5-8). */
 int zk_prove_resident(zk_ctx *ctx, uint8_t *proof_out, size_t cap, size_t *proof_len,
                       uint8_t state_out[32]);
+/* generate_proof(channel: Channel) -> Proof (prover.rs:9) literally: proves the resident trace on the CALLER'S
+ * channel (channel.rs:6-37).  Every commitment is appended to `ch` and every challenge is drawn from it, so a
+ * channel that already holds a transcript prefix yields the proof bound to that prefix; Proof{state, data}
+ * (proof.rs:5-8, channel.rs:34-36) is then zk_channel_state / zk_channel_data.  With a fresh channel
+ * (main.rs:19) the bytes equal zk_prove_resident's. */
+int zk_prove_channel(zk_ctx *ctx, zk_channel *ch);
 /* zk_prove_resident on `count` (1..16) distinct contexts at once, one host thread each: the latency-bound
  * phases of one proof overlap the hashing of the others on the same GPU.  Proof i goes to
  * proofs_out + i*stride (stride >= the proof length), its length to lens_out[i], its state to
@@ -179,7 +188,8 @@ int zk_kernel_stats(zk_ctx *ctx, zk_kernel_stat *out, size_t count, int reset);
  * lockstep: the layers of the batch are stored proof-major, so every stage is ONE launch of the kernels
  * a single proof uses on a domain batch times larger, and the trees of the batch are the bottom of one
  * heap whose nodes of depth log_batch are the per-proof roots.  Every proof is byte-identical to what
- * zk_prove returns for the same trace.  log_batch <= 10, log_blowup >= 1. */
+ * zk_prove returns for the same trace.  log_batch <= 10; (log_n, log_blowup) as for zk_ctx_create (log_n >= 2, != 3), so
+ * every proof a batch produces can be checked by zk_verify*. */
 typedef struct zk_batch zk_batch;
 int zk_batch_create(int device, uint32_t log_n, uint32_t log_blowup, uint32_t log_batch, zk_batch **out);
 int zk_batch_destroy(zk_batch *b);
@@ -227,6 +237,9 @@ int zk_compute_root_from_path_ex(uint32_t element, size_t index, const uint8_t *
 /* ---- Channel (channel.rs:6-37), host only ------------------------------------ */
 int zk_channel_new(zk_channel **out);                                        /* channel.rs:12 */
 int zk_channel_free(zk_channel *ch);
+/* Adopts the two fields of a Channel kept on the caller's side (channel.rs:6-9: state, data): how the reference's
+ * Rust Channel argument of generate_proof (prover.rs:9) crosses the FFI; read back with zk_channel_state / _data. */
+int zk_channel_import(zk_channel *ch, const uint8_t state[32], const uint8_t *data, size_t n);
 int zk_channel_commit(zk_channel *ch, const uint8_t *bytes, size_t n);       /* channel.rs:19 */
 int zk_channel_get_u32(zk_channel *ch, uint32_t *out);                       /* channel.rs:28 */
 int zk_channel_state(const zk_channel *ch, uint8_t out[32]);
@@ -245,6 +258,66 @@ int zk_tail_create(int device, uint32_t log_n_tail, uint32_t log_blowup, uint32_
 int zk_tail_run(zk_ctx *tail, const uint32_t *d_layer0, void *src_stream, zk_channel *ch, int hash_kind,
                 uint32_t *betas_out, uint8_t *roots_out, uint32_t *free_term_out);
 int zk_tail_open(zk_ctx *tail, size_t x, uint32_t *vals_out, uint8_t *paths_out);
+
+/* ---- one proof sharded over the GPUs of one node (BASELINE.json configs[3]) ----------------
+ * generate_proof (prover.rs:9-293) with the evaluation domain distributed CYCLICALLY over `world` ranks, one process
+ * (or thread) per GPU: rank r holds the elements i = r (mod world) of every layer, which is again a coset domain, so
+ * LDE, composition and every fold run the single-GPU kernels with no communication.  The only exchange is the
+ * commitment: one all-to-all per committed layer turns the cyclic layout into contiguous leaf blocks (the transpose
+ * of a four-step NTT over the ranks), each rank hashes its subtree, the `world` subtree roots are exchanged and the
+ * top log2(world) levels are hashed on the host.  Layers below 2^22 values are replicated and finished by every rank
+ * (zk_tail_*).  Every rank runs the same transcript and returns the same proof bytes, identical to zk_prove's.
+ *
+ * Transport.  By default the collectives are RCCL's (librccl.so.1 is loaded at run time; grouped ncclSend/ncclRecv for
+ * the all-to-all, ncclAllGather): rank 0 calls zk_shard_unique_id, the caller distributes the 128 bytes (any side
+ * channel: MPI, a file, torch.distributed) and every rank passes them to zk_shard_create.  A caller that owns its own
+ * communication passes a zk_shard_transport instead (device pointers, stream-ordered on `stream`); tests use that to
+ * run several ranks on one GPU.  world must be a power of two dividing the blow-up. */
+typedef struct zk_shard zk_shard;
+#define ZK_SHARD_ID_BYTES 128
+typedef struct zk_shard_transport {
+    void *user;
+    /* send[p] (words u32) goes to rank p, recv[q] (words u32) comes from rank q; p, q < world, own part included */
+    int (*all_to_all)(void *user, const uint32_t *const *send, uint32_t *const *recv, size_t words, void *stream);
+    /* recv[q * words ..] = rank q's send */
+    int (*all_gather)(void *user, const uint32_t *send, uint32_t *recv, size_t words, void *stream);
+} zk_shard_transport;
+typedef struct zk_shard_options {   /* zero = default */
+    uint32_t min_layer_log;     /* a FRI layer stays sharded while it has >= 2^this values in total (22) */
+    uint32_t min_chunk_log;     /* ... and >= 2^this leaves per (rank, peer) piece (14) */
+    uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (22) */
+    int force_collectives;      /* run the collectives even with world = 1 (exercises the transport on one GPU) */
+    int no_root_board;          /* exchange subtree roots with an all-gather instead of the shared-memory board */
+} zk_shard_options;
+typedef struct zk_shard_stats {
+    uint32_t sharded_layers;    /* FRI layers 0 .. sharded_layers-1 (and f) are distributed; the rest is the replicated tail */
+    uint32_t root_board;        /* 1: subtree roots travel through shared memory (all ranks on one node) */
+    uint32_t chunked_layers;    /* layers of the last proof exchanged in chunks overlapped with the hashing */
+    uint32_t native_rccl;       /* 1: the built-in RCCL transport */
+    double sent_bytes;          /* bytes this rank sent to OTHER ranks during the last zk_shard_prove* / lde_commit */
+    double all_to_all_bytes;    /* ... of which in the per-commitment all-to-alls */
+    double setup_ms;
+    double device_bytes;
+} zk_shard_stats;
+/* ncclGetUniqueId through the same run-time loaded RCCL (rank 0, before zk_shard_create). */
+int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]);
+/* Collective over the `world` ranks (ncclCommInitRank when transport is NULL).  id: the shared 128 bytes; with a
+ * caller transport they only name the shared-memory root board (NULL: no board).  opt may be NULL. */
+int zk_shard_create(int device, int rank, int world, const uint8_t *id, const zk_shard_transport *transport,
+                    const zk_shard_options *opt, uint32_t log_n, uint32_t log_blowup, zk_shard **out);
+int zk_shard_destroy(zk_shard *s);
+/* The same n-1 trace values on every rank (prover.rs:32-39; the interpolant is replicated). */
+int zk_shard_trace_upload(zk_shard *s, const uint32_t *trace, size_t count);
+/* generate_proof on the caller's channel (prover.rs:9), collectively; every rank gets the same transcript. */
+int zk_shard_prove_channel(zk_shard *s, zk_channel *ch);
+int zk_shard_prove(zk_shard *s, uint8_t *proof_out, size_t cap, size_t *proof_len, uint8_t state_out[32]);
+/* configs[3] shape: sharded LDE, all-to-all transpose, Merkle commit; root of f_eval (prover.rs:60-85). */
+int zk_shard_lde_commit(zk_shard *s, uint8_t root_out[32]);
+int zk_shard_last_transcript(const zk_shard *s, zk_transcript_info *out);
+/* This rank's shard of a layer (0 = f_eval, 1 + r = FRI layer r < sharded_layers): element j is global index
+ * rank + world * j. */
+int zk_shard_layer_read(zk_shard *s, uint32_t layer, size_t offset, size_t count, uint32_t *out);
+int zk_shard_get_stats(const zk_shard *s, zk_shard_stats *out);
 
 /* Timing of the zk_dev_* launches (process-wide; same classes and semantics as
  * zk_ctx_set_profiling / zk_kernel_stats). */
@@ -304,7 +377,8 @@ int zk_dev_merkle_build_interleaved(const uint32_t *d_recv, uint32_t log_parts, 
  * zk_dev_merkle_build_ex (log_parts = 0, d_src in natural order) or zk_dev_merkle_build_interleaved
  * (log_parts > 0).  With SHA-256 and SHA extensions on the CPU the device stops at depth 8, the calling
  * thread hashes the 255 nodes above (see zk_ctx_set_host_levels) and a copy ordered on `stream` completes
- * d_nodes; the call returns once the root is known.  One committer per host thread. */
+ * d_nodes; the call returns once the root is known.  One committer per host thread;
+ * consecutive commits may use different streams (the staging buffer of the previous commit is released by an event). */
 typedef struct zk_committer zk_committer;
 int zk_committer_create(int device, zk_committer **out);
 int zk_committer_destroy(zk_committer *k);

@@ -78,6 +78,8 @@ def lib():
         L.orc_fieldhash_permute.restype = None; L.orc_fieldhash_permute.argtypes = [vp]
         L.orc_prove.restype = C.c_int
         L.orc_prove.argtypes = [u32, u32, u32, u32, C.c_int, vp, sz, C.POINTER(sz), vp, C.POINTER(_Debug)]
+        L.orc_prove_prefixed.restype = C.c_int
+        L.orc_prove_prefixed.argtypes = [vp, sz, u32, u32, u32, u32, vp, sz, C.POINTER(sz), vp]
         L.orc_verify.restype = C.c_int; L.orc_verify.argtypes = [vp, sz, u32, u32, u32]
         L.orc_set_queries.restype = None; L.orc_set_queries.argtypes = [u32]
         L.orc_proof_size.restype = sz; L.orc_proof_size.argtypes = [sz]
@@ -250,7 +252,7 @@ class ProveResult:
     pass
 
 
-def prove(log_n=10, log_b=3, a0=1, a1=3141592, mode=MODE_NTT, want_vectors=True):
+def prove(log_n=10, log_b=3, a0=1, a1=3141592, mode=MODE_NTT, want_vectors=True, want_roots=False):
     n, N, R = 1 << log_n, 1 << (log_n + log_b), log_n
     cap = lib().orc_proof_data_len(log_n, log_b)
     buf = np.zeros(cap, dtype=np.uint8)
@@ -265,6 +267,9 @@ def prove(log_n=10, log_b=3, a0=1, a1=3141592, mode=MODE_NTT, want_vectors=True)
         res.roots = np.zeros((R + 2, 32), dtype=np.uint8)
         dbg.trace, dbg.f_eval = res.trace.ctypes.data, res.f_eval.ctypes.data
         dbg.cp_layers, dbg.roots = res.cp_flat.ctypes.data, res.roots.ctypes.data
+    elif want_roots:                 # the R + 2 Merkle roots only (large domains: no layer copies)
+        res.roots = np.zeros((R + 2, 32), dtype=np.uint8)
+        dbg.roots = res.roots.ctypes.data
     rc = lib().orc_prove(log_n, log_b, a0, a1, mode, _ptr(buf), cap, C.byref(plen), _ptr(state), C.byref(dbg))
     res.rc = rc
     res.proof = bytes(buf[:plen.value])
@@ -279,6 +284,18 @@ def prove(log_n=10, log_b=3, a0=1, a1=3141592, mode=MODE_NTT, want_vectors=True)
             res.cp_layers.append(res.cp_flat[off:off + (N >> r)])
             off += N >> r
     return res
+
+
+def prove_prefixed(prefix: bytes, log_n=10, log_b=3, a0=1, a1=3141592):
+    """generate_proof on a channel that committed `prefix` first: returns (Channel.data, Channel.state)."""
+    cap = len(prefix) + lib().orc_proof_data_len(log_n, log_b)
+    buf = np.zeros(cap, dtype=np.uint8)
+    state = np.zeros(32, dtype=np.uint8)
+    plen = C.c_size_t(0)
+    rc = lib().orc_prove_prefixed(prefix, len(prefix), log_n, log_b, a0, a1, _ptr(buf), cap, C.byref(plen), _ptr(state))
+    if rc:
+        raise ValueError(f"orc_prove_prefixed failed: {rc}")
+    return bytes(buf[:plen.value]), bytes(state)
 
 
 def verify(proof: bytes, log_n, log_b, public_last):

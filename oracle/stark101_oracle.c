@@ -1012,6 +1012,23 @@ int orc_prove(uint32_t log_n, uint32_t log_b, uint32_t a0, uint32_t a1, int mode
     return rc;
 }
 
+/* generate_proof(channel) (prover.rs:9) on a channel that already holds a committed prefix: the caller's
+ * channel is an argument of the reference's prover, so whatever it absorbed before binds the proof.
+ * `prefix` is committed first (one Channel::commit, channel.rs:19-26), then the prover runs on the same
+ * channel; proof_out receives the whole Channel.data (prefix included, channel.rs:34-36). */
+int orc_prove_prefixed(const uint8_t *prefix, size_t prefix_len, uint32_t log_n, uint32_t log_b, uint32_t a0, uint32_t a1,
+                       uint8_t *proof_out, size_t cap, size_t *proof_len, uint8_t final_state[32]) {
+    if (log_n < 2 || log_b < 1 || log_n + log_b > 30 || log_n == 3) return -100;
+    orc_channel ch; orc_channel_new(&ch);
+    if (prefix_len) orc_channel_commit_bytes(&ch, prefix, prefix_len);
+    int rc = prove_ntt(log_n, log_b, a0, a1, &ch, NULL);
+    if (proof_len) *proof_len = ch.len;
+    if (proof_out) { if (ch.len <= cap) memcpy(proof_out, ch.data, ch.len); else rc = -102; }
+    if (final_state) memcpy(final_state, ch.state, 32);
+    orc_channel_free(&ch);
+    return rc;
+}
+
 /* ======================================================================== */
 /* proof.rs: verify()                                                       */
 /* ======================================================================== */

@@ -130,6 +130,9 @@ typedef struct orc_debug {
 int orc_prove(uint32_t log_n, uint32_t log_b, uint32_t a0, uint32_t a1, int mode,
               uint8_t *proof_out, size_t cap, size_t *proof_len, uint8_t final_state[32],
               orc_debug *dbg);
+/* The same prover on a channel that first commits `prefix` (generate_proof takes the caller's Channel, prover.rs:9). */
+int orc_prove_prefixed(const uint8_t *prefix, size_t prefix_len, uint32_t log_n, uint32_t log_b, uint32_t a0, uint32_t a1,
+                       uint8_t *proof_out, size_t cap, size_t *proof_len, uint8_t final_state[32]);
 /* Proof::verify (proof.rs:15-149) generalised; returns 0 if accepted, else the
  * negative number of the first failing check. */
 int orc_verify(const uint8_t *data, size_t len, uint32_t log_n, uint32_t log_b,

@@ -1,0 +1,63 @@
+// board_check.cpp -- csrc/board.hpp (the shared-memory exchange of subtree roots between the ranks of the
+// sharded prover) under ThreadSanitizer / ASan (tests/test_host_sanitizers.py).  G threads stand in for G
+// processes: each maps the same POSIX shared-memory object and runs thousands of exchanges with skewed timing;
+// every rank must read, for every exchange, exactly what every other rank posted for THAT exchange.
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+#include "../zkstark_amd/csrc/board.hpp"
+
+using zk::impl::RootBoard;
+
+static int run(int G, int rounds) {
+    char name[64];
+    snprintf(name, sizeof name, "/zkstark_amd_boardcheck_%d_%d", (int)getpid(), G);
+    std::vector<RootBoard> boards(G);
+    if (!boards[0].open_or_create(name, 0, G, true)) { fprintf(stderr, "create failed\n"); return 1; }
+    for (int r = 1; r < G; ++r)
+        if (!boards[r].open_or_create(name, r, G, false)) { fprintf(stderr, "open failed\n"); return 1; }
+    shm_unlink(name);
+    std::vector<int> bad(G, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; ++r)
+        th.emplace_back([&, r] {
+            std::vector<uint32_t> all((size_t)G * 8);
+            for (int s = 1; s <= rounds; ++s) {
+                uint32_t mine[8];
+                for (int i = 0; i < 8; ++i) mine[i] = (uint32_t)s * 2654435761u + (uint32_t)(r * 8 + i);
+                if ((s + r) % 37 == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));   // a slow rank
+                if (!boards[r].exchange((uint32_t)s, mine, all.data(), 30.0)) { bad[r] = 1; return; }
+                for (int q = 0; q < G; ++q)
+                    for (int i = 0; i < 8; ++i)
+                        if (all[(size_t)q * 8 + i] != (uint32_t)s * 2654435761u + (uint32_t)(q * 8 + i)) { bad[r] = 2; return; }
+            }
+        });
+    for (auto& t : th) t.join();
+    for (auto& b : boards) b.close();
+    for (int r = 0; r < G; ++r)
+        if (bad[r]) { fprintf(stderr, "G = %d: rank %d failed (%d)\n", G, r, bad[r]); return 1; }
+    // a second user cannot open an object of another size
+    RootBoard a, b;
+    if (!a.open_or_create(name, 0, 2, true)) return 1;
+    if (b.open_or_create(name, 1, 4, false)) { fprintf(stderr, "size mismatch accepted\n"); return 1; }
+    shm_unlink(name);
+    a.close();
+    return 0;
+}
+
+int main() {
+    for (int G : {1, 2, 4, 8})
+        if (run(G, G == 8 ? 1500 : 4000)) return 1;
+    // timeout: a rank that never posts
+    RootBoard lone;
+    char name[64];
+    snprintf(name, sizeof name, "/zkstark_amd_boardcheck_%d_t", (int)getpid());
+    if (!lone.open_or_create(name, 0, 2, true)) return 1;
+    shm_unlink(name);
+    uint32_t mine[8] = {0}, all[16];
+    if (lone.exchange(1, mine, all, 0.2)) { fprintf(stderr, "exchange with a dead rank returned\n"); return 1; }
+    lone.close();
+    printf("board ok\n");
+    return 0;
+}

@@ -30,6 +30,46 @@ def test_header_symbols_are_exported(zk):
     assert set(_lib.SYMBOLS) == set(syms), set(_lib.SYMBOLS) ^ set(syms)
 
 
+def test_rust_surface_is_generated_from_the_header():
+    """bindings/rust/zkstark_amd_sys.rs is generated from include/zkstark_amd.h (tools/gen_rust_sys.py): the
+    committed file is current and declares every function of the header (the Rust drop-in of prover.rs:9)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.generate()
+    committed = open(gen.OUT).read()
+    assert committed == text, "bindings/rust/zkstark_amd_sys.rs is out of date: run python tools/gen_rust_sys.py"
+    assert gen.declared_functions(committed) == header_symbols()
+    # the wrapper uses only declared functions, and the caller's channel is not discarded
+    wrapper = open(os.path.join(ROOT, "bindings", "rust", "prover.rs")).read()
+    used = set(re.findall(r"\b(zk_[a-z0-9_]+)\(", wrapper))
+    assert used <= set(header_symbols()) and "zk_prove_channel" in used and "(_channel:" not in wrapper and "(channel: Channel)" in wrapper
+
+
+def test_channel_import_adopts_state_and_data(zk):
+    """zk_channel_import: the (state, data) of a Channel kept on the caller's side (channel.rs:6-9)."""
+    import ctypes as C
+    from zkstark_amd import _lib
+    a = zk.Channel()
+    a.commit(bytes(range(32)))
+    a.get_u32()
+    b = zk.Channel()
+    _lib.check(_lib.load().zk_channel_import(b._h, a.state, a.data, len(a.data)))
+    assert b.state == a.state and b.data == a.data
+    assert a.get_u32() == b.get_u32() and a.state == b.state and a.data == b.data
+
+
+def test_oracle_prefixed_prover_reduces_to_plain(orc):
+    """orc_prove_prefixed with an empty prefix is orc_prove; a prefix changes every challenge."""
+    base = orc.prove(6, 2, want_vectors=False)
+    data, state = orc.prove_prefixed(b"", 6, 2)
+    assert data == base.proof and state == base.state
+    data2, state2 = orc.prove_prefixed(b"session 7", 6, 2)
+    assert data2[:9] == b"session 7" and data2[9:9 + 32] == base.proof[:32]      # same f_eval root, committed after the prefix
+    assert data2[9 + 32:9 + 36] != base.proof[32:36] and state2 != base.state      # alpha0 already differs
+
+
 def test_product_does_not_touch_the_oracle():
     """The shipped package must not import, link or load anything under oracle/."""
     pkg = os.path.join(ROOT, "zkstark_amd")

@@ -3,6 +3,7 @@
 All calls go through the C ABI (ctypes -> libzkstark_amd.so).
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -158,6 +159,31 @@ def test_prover_rejects_bad_trace(zk):
             ctx.prove(a)
 
 
+def test_prove_channel_uses_the_callers_channel(zk, orc):
+    """generate_proof(channel) (prover.rs:9): zk_prove_channel proves on the caller's Channel.  A fresh channel
+    gives zk_prove's bytes; a channel with a committed prefix gives the oracle's bytes for the same prefix."""
+    for log_n, log_b in ((10, 3), (6, 2), (13, 3)):
+        a = zk.trace_fibsq((1 << log_n) - 1)
+        with zk.Context(log_n, log_b) as ctx:
+            ctx.trace_upload(a)
+            plain = ctx.prove()
+            p0 = ctx.prove_channel(zk.Channel())
+            assert p0.data == plain.data and p0.state == plain.state
+            for prefix in (b"x", b"session 7: " + bytes(range(40))):
+                ch = zk.Channel()
+                ch.commit(prefix)
+                p1 = ctx.prove_channel(ch)
+                want_data, want_state = orc.prove_prefixed(prefix, log_n, log_b)
+                assert p1.data == want_data and p1.state == want_state
+                assert p1.data[len(prefix):len(prefix) + 32] == plain.data[:32] and p1.data[len(prefix) + 32:] != plain.data[32:]
+            # an imported channel (the Rust wrapper's path) behaves the same
+            from zkstark_amd import _lib
+            src = zk.Channel(); src.commit(b"x")
+            imp = zk.Channel()
+            _lib.check(_lib.load().zk_channel_import(imp._h, src.state, src.data, len(src.data)))
+            assert ctx.prove_channel(imp).data == orc.prove_prefixed(b"x", log_n, log_b)[0]
+
+
 # ---- BASELINE.json full sizes ------------------------------------------------------------
 def test_config2_lde_commit_domain_2e20(zk, orc):
     """configs[1]: domain 2^20 LDE + Merkle commit, bit-exact vs the CPU oracle (values and root)."""
@@ -173,14 +199,16 @@ def test_config2_lde_commit_domain_2e20(zk, orc):
 
 
 def test_config3_full_prover_domain_2e24(zk, orc):
-    """configs[2] at full size: the oracle is too slow for the whole proof, so anchor the first
-    commitment on it (f_eval digest and root, bit-exact) and check the rest through the verifier
-    (fold equations at the query, every authentication path) and the free-term constancy."""
+    """configs[2] at full size, bit-exact against the CPU oracle: the proof bytes, the final channel state,
+    every one of the 23 Merkle roots (each feeds the channel: prover.rs:81-85, :176-180, :214-224), every
+    challenge, and the whole f_eval vector.  This is the size that reaches the three radix-128 NTT passes, the
+    multi-launch subtree chain, indexing above 2^31 bytes and the host hand-over with 2^24 leaves."""
     log_n, log_b = 21, 3
     a = zk.trace_fibsq((1 << log_n) - 1)
-    orc.set_threads(16)
+    orc.set_threads(os.cpu_count() or 1)
+    want = orc.prove(log_n, log_b, want_vectors=False, want_roots=True)
+    assert want.rc == 0
     want_f = orc.lde(a, log_n, log_b)
-    want_root = bytes(orc.merkle_build(want_f)[0])
     with zk.Context(log_n, log_b) as ctx:
         proof = ctx.prove(a)
         info = ctx.last_transcript()
@@ -188,14 +216,22 @@ def test_config3_full_prover_domain_2e24(zk, orc):
         # idempotence: a second proof from the resident trace is byte-identical
         proof2 = ctx.prove()
         last = ctx.layer_read(1 + log_n)
+        # the same bytes with the whole tree built on the device (no host hand-over)
+        ctx.set_host_levels(0, 0)
+        proof3 = ctx.prove()
     assert np.array_equal(got_f, want_f)
-    assert bytes(info.roots[0]) == want_root
+    for t in range(log_n + 2):
+        assert bytes(info.roots[t]) == bytes(want.roots[t]), f"root of tree {t}"
+    assert list(info.alpha_raw) == want.alpha_raw and list(info.beta_raw)[:log_n] == want.beta_raw
+    assert info.free_term == want.free_term and info.query_raw == want.query_raw
+    assert proof.data == want.proof, "proof bytes differ from the CPU oracle at domain 2^24"
+    assert proof.state == want.state
     assert proof2.data == proof.data and proof2.state == proof.state
+    assert proof3.data == proof.data and proof3.state == proof.state
     assert len(set(int(v) for v in last)) == 1 and int(last[0]) == info.free_term
     assert len(proof.data) == 32 + 12 + 32 + 21 * 36 + 8 + 4 * (12 + 32 * 24) + sum(8 + 2 * (8 + 32 * (24 - i)) for i in range(21))
     proof.verify()
     assert orc.verify(proof.data, log_n, log_b, int(a[-1])) == 0
-    # linearity of the committed FRI layers in beta is covered at small sizes; here: a tampered proof fails
     bad = bytearray(proof.data)
     bad[-5] ^= 1
     with pytest.raises(zk.ZkError):
@@ -545,6 +581,13 @@ def test_batch_prover_rejects_a_bad_trace(zk):
         zk.BatchContext(10, 3, 11)
     with pytest.raises(zk.ZkError):
         zk.BatchContext(10, 0, 2)
+    # the batch accepts exactly the sizes a context accepts (everything it proves must be verifiable)
+    for log_n, log_b in ((1, 1), (1, 3), (3, 3), (28, 3)):
+        with pytest.raises(zk.ZkError) as e1:
+            zk.BatchContext(log_n, log_b, 1)
+        with pytest.raises(zk.ZkError) as e2:
+            zk.Context(log_n, log_b)
+        assert e1.value.code == e2.value.code == -1
 
 
 def test_maximum_domain_2e30(zk):

@@ -1,0 +1,165 @@
+"""The native sharded prover (zk_shard_*, csrc/shard.hip) on real hardware, through the C ABI.
+
+* world = 1 with the built-in RCCL transport and the collectives forced: grouped ncclSend/ncclRecv all-to-all,
+  ncclAllGather, the chunked exchange on the side stream -- everything a one-GPU box lets RCCL do;
+* world = 2 / 4 as processes sharing the one GPU, with a caller-supplied transport (gloo, host-staged): the same
+  orchestration code, every rank's proof bit-exact against the CPU oracle;
+* BASELINE.json configs[3]: domain 2^26 evaluated by 2 ranks + all-to-all transpose + commit, root anchored on
+  the oracle (orc.lde + orc.merkle_build).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+@pytest.mark.parametrize("log_n,log_b,opts", [
+    (10, 3, dict(min_layer_log=1, min_chunk_log=4)),
+    (13, 3, dict(min_layer_log=1, min_chunk_log=6, overlap_min_log=10)),      # chunked exchange + commit_finish
+    (16, 2, dict(min_layer_log=12, min_chunk_log=6, overlap_min_log=12)),
+    (18, 3, dict()),                                                           # the production thresholds
+])
+def test_shard_world1_rccl_matches_oracle(zk, orc, log_n, log_b, opts):
+    """One rank, RCCL transport, collectives forced: proof bytes == oracle; the byte counters see no peer."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    want = orc.prove(log_n, log_b, want_vectors=False, want_roots=True)
+    uid = zk.shard_unique_id()
+    with zk.ShardContext(log_n, log_b, 0, 1, uid, force_collectives=True, **opts) as sp:
+        sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        proof = sp.prove()
+        info = sp.last_transcript()
+        st = sp.stats()
+        again = sp.prove()
+        ch = zk.Channel(); ch.commit(b"prefix")
+        pref = sp.prove_channel(ch)
+    assert proof.data == want.proof and proof.state == want.state
+    assert again.data == proof.data
+    for t in range(log_n + 2):
+        assert bytes(info.roots[t]) == bytes(want.roots[t]), t
+    assert list(info.beta_raw)[:log_n] == want.beta_raw and info.free_term == want.free_term
+    assert st["native_rccl"] == 1 and st["sent_bytes"] == 0 and st["sharded_layers"] >= 1
+    if "overlap_min_log" in opts:
+        assert st["chunked_layers"] >= 2
+    assert (pref.data, pref.state) == orc.prove_prefixed(b"prefix", log_n, log_b)
+    proof.verify(strict=True)
+
+
+def test_shard_world1_local_no_collectives(zk, orc):
+    """world = 1 without forcing: no transport call at all (RCCL is not even loaded for it)."""
+    from zkstark_amd import _lib
+    boom = _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(lambda *a: 7), _lib.ALL_GATHER_FN(lambda *a: 7))
+    want = orc.prove(12, 3, want_vectors=False)
+    with zk.ShardContext(12, 3, 0, 1, None, transport=boom, min_layer_log=1, min_chunk_log=5) as sp:
+        sp.trace_upload(zk.trace_fibsq((1 << 12) - 1))
+        proof = sp.prove()
+    assert proof.data == want.proof and proof.state == want.state
+
+
+def test_shard_argument_checks(zk):
+    from zkstark_amd import _lib
+    t = _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(lambda *a: 0), _lib.ALL_GATHER_FN(lambda *a: 0))
+    for world, rank, log_n, log_b in ((3, 0, 12, 3), (16, 0, 12, 3), (2, 2, 12, 3), (2, 0, 3, 3), (4, 0, 4, 2)):
+        with pytest.raises(zk.ZkError) as e:
+            zk.ShardContext(log_n, log_b, rank, world, None, transport=t)
+        assert e.value.code == -1
+    with pytest.raises(zk.ZkError):                       # the RCCL transport needs the shared id
+        zk.ShardContext(12, 3, 0, 1, None)
+    with zk.ShardContext(12, 3, 0, 1, None, transport=t, min_layer_log=1, min_chunk_log=5) as sp:
+        with pytest.raises(zk.ZkError) as e:              # prove without a trace
+            sp.prove()
+        assert e.value.code == -4
+        with pytest.raises(zk.ZkError):
+            sp.trace_upload(np.ones(5, dtype=np.uint32))
+
+
+def _worker(rank, world, port, log_n, log_b, opts, q, mode, uid):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zkstark_amd as zk
+        from sharded_testlib import gloo_transport
+        torch.cuda.set_device(0)
+        tp = gloo_transport()
+        with zk.ShardContext(log_n, log_b, rank, world, uid, transport=tp, **opts) as sp:
+            sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+            if mode == "prove":
+                proof = sp.prove()
+                info = sp.last_transcript()
+                q.put((rank, proof.data, proof.state, [bytes(r) for r in info.roots[:log_n + 2]], sp.stats()))
+            else:
+                root = sp.lde_commit()
+                again = sp.lde_commit()
+                q.put((rank, root, again, sp.layer_read(0, 0, 4).tolist(), sp.stats()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, log_n, log_b, opts, mode, timeout=900):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    uid = os.urandom(128)                                  # names the shared-memory root board (no RCCL here)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, opts, q, mode, uid)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=timeout) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("world,log_n,log_b,opts", [
+    (2, 12, 3, dict(min_layer_log=1, min_chunk_log=6)),
+    (4, 14, 3, dict(min_layer_log=1, min_chunk_log=6)),
+    (2, 16, 3, dict(min_layer_log=1, min_chunk_log=6, overlap_min_log=10)),          # chunked exchange, 2 ranks
+    (4, 16, 2, dict(min_layer_log=10, min_chunk_log=6, overlap_min_log=10)),         # world = blow-up: local blow-up 1
+    (2, 14, 3, dict(min_layer_log=1, min_chunk_log=6, no_root_board=True)),          # roots by all-gather
+])
+def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
+    """Every rank's proof, state and all R + 2 roots equal the CPU oracle's; the exchanged volume is what
+    DESIGN.md section 6 states: 4 bytes per element per distributed layer, a share (G-1)/G of it to peers."""
+    want = orc.prove(log_n, log_b, want_vectors=False, want_roots=True)
+    out = _run(world, log_n, log_b, opts, "prove")
+    N = 1 << (log_n + log_b)
+    for rank, data, state, roots, st in out:
+        assert data == want.proof and state == want.state, f"rank {rank}"
+        assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
+        ns = st["sharded_layers"]
+        assert ns >= 2 and st["root_board"] == (0 if opts.get("no_root_board") else 1) and st["native_rccl"] == 0
+        words = N + sum(N >> rho for rho in range(ns))              # f and FRI layers 0 .. ns-1, one all-to-all each
+        assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world
+        if "overlap_min_log" in opts:
+            assert st["chunked_layers"] >= 2
+
+
+def test_config4_native_sharded_lde_transpose_commit_2e26(zk, orc):
+    """configs[3]: domain 2^26, each of 2 ranks evaluates its cosets (no communication), one all-to-all
+    transposes to natural order (chunked, overlapped with the hashing), subtrees + host top.  The root is the
+    CPU oracle's (orc.lde + orc.merkle_build), the shards are the oracle's values at i = rank (mod 2)."""
+    log_n, world = 23, 2
+    a = zk.trace_fibsq((1 << log_n) - 1)
+    orc.set_threads(os.cpu_count() or 1)
+    want_f = orc.lde(a, log_n, 3)
+    want_root = bytes(orc.merkle_build(want_f)[0])
+    out = _run(world, log_n, 3, {}, "lde_commit", timeout=1200)
+    for rank, root, again, head, st in out:
+        assert root == want_root and again == want_root, f"rank {rank}"
+        assert head == [int(want_f[rank + world * j]) for j in range(4)]
+        assert st["chunked_layers"] == 1 and st["all_to_all_bytes"] == 4.0 * (1 << 26) / world / world

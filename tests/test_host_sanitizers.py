@@ -44,3 +44,15 @@ def test_batch_pool_under_sanitizers(tmp_path, san):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "pool ok" in out.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_root_board_under_sanitizers(tmp_path, san):
+    """The shared-memory exchange of subtree roots between the ranks of the sharded prover (csrc/board.hpp):
+    1-8 ranks, thousands of exchanges with skewed timing, size mismatch, a dead rank (timeout)."""
+    exe = str(tmp_path / "board_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", f"-fsanitize={san}", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "board_check.cpp"), "-o", exe, "-lrt"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "board ok" in out.stdout

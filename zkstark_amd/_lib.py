@@ -31,6 +31,25 @@ class KernelStat(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double), ("ops", C.c_double)]
 
 
+# zk_shard_transport: the two collectives of the sharded prover, supplied by the caller (tests: gloo-staged)
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class ShardTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all", ALL_TO_ALL_FN), ("all_gather", ALL_GATHER_FN)]
+
+
+class ShardOptions(C.Structure):
+    _fields_ = [("min_layer_log", C.c_uint32), ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32),
+                ("force_collectives", C.c_int), ("no_root_board", C.c_int)]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
+                ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double)]
+
+
 KERNEL_CLASSES = ("ntt", "merkle_leaf", "merkle_inner", "merkle_top", "compose", "fri_fold", "gather")
 
 
@@ -40,6 +59,7 @@ _cp = C.c_char_p
 SYMBOLS = {
     "zk_last_error": (_cp, []),
     "zk_version": (_cp, []),
+    "zk_build_hash": (_cp, []),
     "zk_field_add": (_u32, [_u32, _u32]),
     "zk_field_sub": (_u32, [_u32, _u32]),
     "zk_field_mul": (_u32, [_u32, _u32]),
@@ -77,6 +97,7 @@ SYMBOLS = {
     "zk_merkle_node": (_int, [_vp, _u32, _sz, _vp]),
     "zk_merkle_path": (_int, [_vp, _u32, _sz, _vp, C.POINTER(_sz)]),
     "zk_prove_resident": (_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "zk_prove_channel": (_int, [_vp, _vp]),
     "zk_prove_many": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "zk_prove": (_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
@@ -108,6 +129,7 @@ SYMBOLS = {
     "zk_compute_root_from_path": (_int, [_u32, _sz, _vp, _sz, _vp]),
     "zk_channel_new": (_int, [C.POINTER(_vp)]),
     "zk_channel_free": (_int, [_vp]),
+    "zk_channel_import": (_int, [_vp, _vp, _vp, _sz]),
     "zk_channel_commit": (_int, [_vp, _vp, _sz]),
     "zk_channel_get_u32": (_int, [_vp, C.POINTER(_u32)]),
     "zk_channel_state": (_int, [_vp, _vp]),
@@ -126,6 +148,16 @@ SYMBOLS = {
     "zk_tail_create": (_int, [_int, _u32, _u32, _u32, C.POINTER(_vp)]),
     "zk_tail_run": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_u32)]),
     "zk_tail_open": (_int, [_vp, _sz, _vp, _vp]),
+    "zk_shard_unique_id": (_int, [_vp]),
+    "zk_shard_create": (_int, [_int, _int, _int, _vp, C.POINTER(ShardTransport), C.POINTER(ShardOptions), _u32, _u32, C.POINTER(_vp)]),
+    "zk_shard_destroy": (_int, [_vp]),
+    "zk_shard_trace_upload": (_int, [_vp, _vp, _sz]),
+    "zk_shard_prove_channel": (_int, [_vp, _vp]),
+    "zk_shard_prove": (_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "zk_shard_lde_commit": (_int, [_vp, _vp]),
+    "zk_shard_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
+    "zk_shard_layer_read": (_int, [_vp, _u32, _sz, _sz, _vp]),
+    "zk_shard_get_stats": (_int, [_vp, C.POINTER(ShardStats)]),
     "zk_dev_set_profiling": (_int, [_u32]),
     "zk_dev_kernel_stats": (_int, [_vp, _sz, _int]),
     "zk_dev_merkle_build": (_int, [_vp, _u32, _vp, _vp]),
@@ -136,17 +168,20 @@ _lib = None
 
 
 def load():
-    """Returns the loaded CDLL; builds it first if hipcc is present and the .so is stale."""
+    """Returns the loaded CDLL; builds it first if hipcc is present and the .so is missing or was built from
+    other sources (hash of sources + headers, zk_build_hash); never loads a stale binary silently."""
     global _lib
     if _lib is not None:
         return _lib
+    want = _build.source_hash()
     try:
-        _build.build(if_missing_only=True)   # an existing library is used as is (python -m zkstark_amd.build rebuilds)
-    except Exception as e:  # no hipcc on this box: use the prebuilt .so that travelled with the repo
+        _build.build()                       # rebuilds (under a lock) when the library is missing or built from other sources
+    except Exception as e:                   # no hipcc on this box: only a library built from THIS tree will do
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"libzkstark_amd.so is missing and cannot be built: {e}") from e
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libzkstark_amd.so is missing: run `python -m zkstark_amd.build` (needs hipcc)")
+        if _build.built_hash() != want and os.environ.get("ZK_ALLOW_STALE_LIB") != "1":
+            raise ImportError(f"libzkstark_amd.so was built from other sources ({_build.built_hash()} != {want}) "
+                              f"and cannot be rebuilt here: {e}") from e
     # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME
     # libamdhip64.so.7); if it is loaded first the dynamic loader resolves this library's
     # libamdhip64.so.7 to the same object, so torch tensors, streams and RCCL interoperate with
@@ -159,8 +194,16 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
+    got = lib.zk_build_hash().decode()
+    if got != want and os.environ.get("ZK_ALLOW_STALE_LIB") != "1":
+        raise ImportError(f"libzkstark_amd.so is stale: built from {got}, the tree is {want} (python -m zkstark_amd.build)")
     _lib = lib
     return lib
+
+
+def build_hash():
+    """Hash of the sources the loaded library was built from (also in the bench line)."""
+    return load().zk_build_hash().decode()
 
 
 def check(code):

@@ -158,9 +158,8 @@ int zk_batch_destroy(zk_batch* b) {
 int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_batch, zk_batch** out) {
     if (!out) return fail(ZK_ERR_INVALID, "zk_batch_create: out is null");
     *out = nullptr;
-    if (log_n < 1 || log_n == 3 || log_b < 1 || log_b > 5 || log_batch > kMaxHostLog || log_n + log_b + log_batch > 30)
-        return fail(ZK_ERR_INVALID, "zk_batch_create: need 1 <= log_n != 3, 1 <= log_blowup <= 5, log_batch <= %u, log_n + log_blowup + log_batch <= 30",
-                    kMaxHostLog);
+    if (log_batch > kMaxHostLog) return fail(ZK_ERR_INVALID, "zk_batch_create: need log_batch <= %u", kMaxHostLog);
+    if (int rc0 = check_proof_size("zk_batch_create", log_n, log_b, log_batch)) return rc0;   // the same sizes zk_ctx_create accepts
     HIPCHK(hipSetDevice(device));
     zk_batch* b = new (std::nothrow) zk_batch();
     if (!b) return fail(ZK_ERR_NOMEM, "out of host memory");

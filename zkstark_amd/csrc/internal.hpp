@@ -9,6 +9,12 @@
 #include "../../include/zkstark_amd.h"
 #include "field.hpp"
 #include "kernels.hpp"
+#include "transcript.hpp"
+
+// Channel (channel.rs:6-37) behind the C ABI
+struct zk_channel {
+    zk::Channel ch;
+};
 
 namespace zk {
 namespace impl {
@@ -30,6 +36,19 @@ constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // 
 constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail
 constexpr uint32_t kTileLog = 13;      // 8192 words = 32 KiB per workgroup tile
 constexpr uint32_t kMaxRadixLog = 8;
+
+// Sizes a proof can have: shared by zk_ctx_create and zk_batch_create so that everything the provers accept is something
+// the verifier (transcript.hpp: log_n >= 2) can check.  n = 8 is degenerate: g^4 = -1 cancels the leading terms of
+// f(gx)^2 + f(x)^2, so deg c2 < n-1 and the generalised asserts of prover.rs:156/:169 would fail; n = 2 makes the boundary
+// constraints collide (g^(n-2) = g^0).  Returns 0 or an error already recorded with fail().
+inline int check_proof_size(const char* who, uint32_t log_n, uint32_t log_b, uint32_t log_extra = 0) {
+    if (log_n < 2 || log_b < 1 || log_b > 5 || log_n + log_b + log_extra > 30)
+        return fail(ZK_ERR_INVALID, "%s: need 2 <= log_n, 1 <= log_blowup <= 5, log_n + log_blowup%s <= 30 (got %u, %u)", who,
+                    log_extra ? " + log_batch" : "", log_n, log_b);
+    if (log_n == 3)
+        return fail(ZK_ERR_INVALID, "%s: n = 8 is degenerate for the Fibonacci-square constraints (the degree asserts of prover.rs:156/:169 would fail)", who);
+    return ZK_OK;
+}
 
 // ---- transform plan: the size-2^log_m transform as radix-2^bits[d] passes, d = 0 the slowest storage digit
 struct Plan {

@@ -1,0 +1,650 @@
+// shard.hip -- one proof sharded over the GPUs of one node (zk_shard_*): the host orchestration of
+// prover.rs:9-293 for a cyclically distributed evaluation domain.
+//
+// Rank r of G holds the elements i = r (mod G) of every layer.  Its shard of the coset {w h^i} is the coset
+// {(w h^r) (h^G)^j}, a domain with blow-up B/G, so LDE, composition and every fold are the single-GPU kernels
+// (zk_dev_*) on that domain, with no communication.  A commitment needs the leaves in natural order: one
+// all-to-all turns the cyclic layout into contiguous blocks of m/G leaves (chunk q of the receive buffer comes
+// from rank q; leaf u*G + q of the block = recv[q][u], hashed straight from the receive buffer), each rank builds
+// its subtree, the G subtree roots are exchanged and the top log2(G) levels are hashed on the host by every rank.
+// Small layers are replicated and finished in one call (zk_tail_*).  The transcript runs identically on every rank.
+//
+// The collectives go through a two-function transport: RCCL (grouped ncclSend/ncclRecv over xGMI, loaded at run
+// time) or the caller's own (tests: several ranks on one GPU).
+#include "shard.hpp"
+#include "board.hpp"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "host_sha.hpp"
+#include "sha256.hpp"
+
+using namespace zk;
+using namespace zk::impl;
+
+// ===========================================================================
+// RCCL at run time
+// ===========================================================================
+namespace zk {
+namespace impl {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const RcclApi* rccl_api() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    static RcclApi api;
+    static int state = 0;                   // 0 = not tried, 1 = loaded, -1 = failed
+    static std::string why;
+    if (state == 1) return &api;
+    if (state == -1) { fail(ZK_ERR_STATE, "%s", why.c_str()); return nullptr; }
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) {
+        state = -1;
+        why = std::string("RCCL is not available (dlopen librccl.so.1: ") + dlerror() + "): pass a zk_shard_transport";
+        fail(ZK_ERR_STATE, "%s", why.c_str());
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p) { ok = false; why = std::string("librccl lacks ") + n; } return p; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { state = -1; fail(ZK_ERR_STATE, "%s", why.c_str()); return nullptr; }
+    state = 1;
+    return &api;
+}
+
+}  // namespace impl
+}  // namespace zk
+
+// ===========================================================================
+// The sharded prover
+// ===========================================================================
+struct zk_shard {
+    int device = 0, rank = 0, G = 1;
+    uint32_t lg = 0, log_n = 0, log_b = 0, L = 0, R = 0;
+    size_t n = 0, N = 0, B = 0;
+    hipStream_t stream = nullptr, xstream = nullptr;   // xstream: chunked exchanges run beside the hashing
+    // transport
+    zk_shard_transport tp{};
+    const RcclApi* rccl = nullptr;                     // non-null: tp is the built-in RCCL transport
+    ncclComm_t comm = nullptr;
+    bool force = false;                                // collectives even with G = 1
+    // layout
+    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 22;
+    static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
+    uint32_t n_sharded = 1, tail_rounds = 0;
+    zk_dom* dom_loc = nullptr;
+    zk_ctx* tail = nullptr;
+    zk_committer* committer = nullptr;
+    uint32_t *d_trace = nullptr, *d_coef = nullptr, *d_layers = nullptr, *d_trees = nullptr;
+    uint32_t *d_recv = nullptr, *d_gbuf = nullptr, *d_repl = nullptr, *d_small = nullptr;
+    std::vector<size_t> layer_off, layer_len, tree_off, tree_leaves;
+    hipEvent_t ev_layer = nullptr, ev_chunk[1u << kLogChunks] = {};
+    // decommit
+    uint64_t *d_goff = nullptr, *h_goff = nullptr;
+    uint32_t *d_gout = nullptr, *d_gall = nullptr, *h_gall = nullptr;
+    size_t gather_slots = 0, gather_words = 0;
+    uint32_t* h_small = nullptr;                       // pinned scratch (subtree roots, flags)
+    // root board
+    RootBoard board;
+    bool use_board = false;
+    uint32_t board_seq = 0;
+    // per proof
+    std::vector<std::vector<uint32_t>> tops;           // per tree: heap of 2G-1 digests (8 words each), root first
+    bool have_trace = false;
+    uint32_t first = 0, last = 0;
+    zk_transcript_info info{};
+    zk_shard_stats stats{};
+    double device_bytes = 0;
+};
+
+namespace {
+
+bool sharded(const zk_shard* s, uint32_t rho) { return rho < s->n_sharded; }
+uint32_t* layer_ptr(zk_shard* s, uint32_t lid) { return s->d_layers + s->layer_off[lid]; }
+uint32_t* tree_ptr(zk_shard* s, uint32_t t) { return s->d_trees + s->tree_off[t]; }
+bool collectives(const zk_shard* s) { return s->G > 1 || s->force; }
+
+// ---- built-in transport: RCCL ---------------------------------------------------------------
+#define NCCLCHK(s, expr)                                                                                  \
+    do {                                                                                                  \
+        ncclResult_t _r = (expr);                                                                         \
+        if (_r != ncclSuccess)                                                                            \
+            return fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (s)->rccl->GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+int rccl_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* recv, size_t words, void* stream) {
+    zk_shard* s = static_cast<zk_shard*>(user);
+    hipStream_t st = (hipStream_t)stream;
+    // the all-to-all of the four-step transpose: every pair exchanges one piece, all 7 xGMI links busy at once
+    NCCLCHK(s, s->rccl->GroupStart());
+    for (int p = 0; p < s->G; ++p) {
+        NCCLCHK(s, s->rccl->Send(send[p], words, ncclUint32, p, s->comm, st));
+        NCCLCHK(s, s->rccl->Recv(recv[p], words, ncclUint32, p, s->comm, st));
+    }
+    NCCLCHK(s, s->rccl->GroupEnd());
+    return ZK_OK;
+}
+int rccl_all_gather(void* user, const uint32_t* send, uint32_t* recv, size_t words, void* stream) {
+    zk_shard* s = static_cast<zk_shard*>(user);
+    NCCLCHK(s, s->rccl->AllGather(send, recv, words, ncclUint32, s->comm, (hipStream_t)stream));
+    return ZK_OK;
+}
+
+// ---- collectives with the byte accounting of zk_shard_stats -----------------------------------
+int all_to_all(zk_shard* s, const uint32_t* const* send, uint32_t* const* recv, size_t words, hipStream_t st) {
+    int rc = s->tp.all_to_all(s->tp.user, send, recv, words, (void*)st);
+    if (rc) return rc > 0 ? fail(ZK_ERR_HIP, "transport all_to_all failed (%d)", rc) : rc;
+    const double sent = 4.0 * (double)words * (s->G - 1);
+    s->stats.sent_bytes += sent;
+    s->stats.all_to_all_bytes += sent;
+    return ZK_OK;
+}
+int all_gather(zk_shard* s, const uint32_t* send, uint32_t* recv, size_t words, hipStream_t st) {
+    int rc = s->tp.all_gather(s->tp.user, send, recv, words, (void*)st);
+    if (rc) return rc > 0 ? fail(ZK_ERR_HIP, "transport all_gather failed (%d)", rc) : rc;
+    s->stats.sent_bytes += 4.0 * (double)words * (s->G - 1);
+    return ZK_OK;
+}
+// min over the ranks of a host flag (setup only): one word through the transport
+int agree(zk_shard* s, bool ok, bool* all_ok) {
+    if (!collectives(s)) { *all_ok = ok; return ZK_OK; }
+    s->h_small[0] = ok ? 1u : 0u;
+    HIPCHK(hipMemcpyAsync(s->d_small, s->h_small, 4, hipMemcpyHostToDevice, s->stream));
+    int rc = all_gather(s, s->d_small, s->d_small + 8, 1, s->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->h_small + 8, s->d_small + 8, 4 * (size_t)s->G, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *all_ok = true;
+    for (int q = 0; q < s->G; ++q) *all_ok = *all_ok && s->h_small[8 + q] == 1u;
+    return ZK_OK;
+}
+
+// merkle.rs:38-47 over the G subtree roots (state words): heap of 2G-1 digests, root first
+void host_merkle_top(const uint32_t* subroots, int G, std::vector<uint32_t>& heap) {
+    heap.assign((size_t)(2 * G - 1) * 8, 0);
+    memcpy(heap.data() + (size_t)(G - 1) * 8, subroots, (size_t)G * 32);
+    for (int j = G - 2; j >= 0; --j) host_sha_inner(heap.data() + (size_t)(2 * j + 1) * 8, heap.data() + (size_t)(2 * j + 2) * 8, heap.data() + (size_t)j * 8);
+}
+
+// Cyclic layer `lid` (2^m_log values in total, 2^m_log / G here) -> subtree over this rank's block of leaves;
+// root_out: the root of the whole tree (prover.rs:81, :176, :214 + what :85 / :180 / :224 feed the channel).
+int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[32]) {
+    const int G = s->G;
+    const uint32_t lg = s->lg;
+    uint32_t* loc = layer_ptr(s, lid);
+    const size_t cnt = s->layer_len[lid];
+    uint32_t* nodes = tree_ptr(s, lid);
+    uint8_t mine_bytes[32];
+    int rc;
+    if (collectives(s)) {
+        const uint32_t log_cnt = m_log - 2 * lg;                  // words per (rank, peer) piece
+        const size_t per = cnt >> lg;
+        const uint32_t* send[64];
+        uint32_t* recv[64];
+        if (log_cnt >= s->overlap_min_log && log_cnt >= zk_shard::kLogChunks + 8) {
+            // big layer: exchange and hash in K aligned chunks, so that hashing chunk c overlaps the exchange of
+            // chunk c+1.  The exchanges are issued from a side stream that depends on the layer only.
+            const uint32_t lk = zk_shard::kLogChunks, K = 1u << lk;
+            const size_t cc = per >> lk;                          // words per (peer, chunk)
+            HIPCHK(hipEventRecord(s->ev_layer, s->stream));
+            HIPCHK(hipStreamWaitEvent(s->xstream, s->ev_layer, 0));
+            for (uint32_t c = 0; c < K; ++c) {
+                for (int g = 0; g < G; ++g) {
+                    send[g] = loc + (size_t)g * per + (size_t)c * cc;
+                    recv[g] = s->d_recv + ((size_t)c * G + g) * cc;
+                }
+                if ((rc = all_to_all(s, send, recv, cc, s->xstream))) return rc;
+                HIPCHK(hipEventRecord(s->ev_chunk[c], s->xstream));
+            }
+            for (uint32_t c = 0; c < K; ++c) {
+                HIPCHK(hipStreamWaitEvent(s->stream, s->ev_chunk[c], 0));
+                if ((rc = zk_dev_merkle_build_chunk(s->d_recv + (size_t)c * G * cc, lg, log_cnt - lk, nodes, m_log - lg, c, s->stream, ZK_HASH_SHA256))) return rc;
+            }
+            if ((rc = zk_dev_merkle_commit_finish(s->committer, nodes, m_log - lg, lk, s->stream, ZK_HASH_SHA256, mine_bytes))) return rc;
+            s->stats.chunked_layers += 1;
+        } else {
+            for (int g = 0; g < G; ++g) { send[g] = loc + (size_t)g * per; recv[g] = s->d_recv + (size_t)g * per; }
+            if ((rc = all_to_all(s, send, recv, per, s->stream))) return rc;   // piece q: rank q's share of my block
+            if ((rc = zk_dev_merkle_commit(s->committer, s->d_recv, lg, log_cnt, nodes, s->stream, ZK_HASH_SHA256, mine_bytes))) return rc;
+        }
+    } else {
+        if ((rc = zk_dev_merkle_commit(s->committer, loc, 0, m_log, nodes, s->stream, ZK_HASH_SHA256, mine_bytes))) return rc;
+    }
+    // the G subtree roots, on the host of every rank
+    uint32_t mine[8];
+    Digest dm;
+    bytes_to_digest(mine_bytes, dm);
+    memcpy(mine, dm.w, 32);
+    std::vector<uint32_t> sub((size_t)G * 8);
+    if (!collectives(s)) {
+        memcpy(sub.data(), mine, 32);
+    } else if (s->use_board) {
+        if (!s->board.exchange(++s->board_seq, mine, sub.data()))
+            return fail(ZK_ERR_HIP, "zk_shard: a rank did not post its subtree root (exchange %u timed out)", s->board_seq);
+    } else {
+        if ((rc = all_gather(s, nodes, s->d_small, 8, s->stream))) return rc;   // node 0 of every rank's subtree
+        HIPCHK(hipMemcpyAsync(s->h_small, s->d_small, 32 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        memcpy(sub.data(), s->h_small, 32 * (size_t)G);
+    }
+    host_merkle_top(sub.data(), G, s->tops[lid]);
+    digest_words_to_bytes(s->tops[lid].data(), root_out);
+    return ZK_OK;
+}
+
+int do_lde(zk_shard* s) { return zk_dev_lde(s->dom_loc, s->d_trace, s->d_coef, layer_ptr(s, 0), s->stream); }
+
+// prover.rs:266-289.  Every rank gathers the slots it owns (the same slot list everywhere), one all-gather merges
+// them, every rank assembles the same bytes.
+int decommit(zk_shard* s, Channel& ch, size_t x) {
+    const int G = s->G, me = s->rank;
+    const size_t B = s->B, N = s->N;
+    const uint32_t L = s->L, rho0 = s->n_sharded;
+    struct Item { int owner; uint64_t off; };
+    std::vector<Item> vit, dit;
+    struct Open { size_t nloc; uint32_t lid; size_t block; };
+    std::vector<Open> opens;
+    std::vector<size_t> nodes;
+    auto add_opening = [&](uint32_t lid, size_t leaf, uint32_t m_log) {
+        const size_t blk = ((size_t)1 << m_log) >> s->lg;
+        const size_t p = leaf / blk, lf = leaf % blk;
+        vit.push_back({(int)(leaf % (size_t)G), (uint64_t)(s->layer_off[lid] + leaf / (size_t)G)});
+        nodes.clear();
+        path_nodes(blk, lf, nodes);
+        for (size_t nd : nodes) dit.push_back({(int)p, (uint64_t)s->tree_off[lid] + (uint64_t)nd * 8});
+        opens.push_back({nodes.size(), lid, p});
+    };
+    add_opening(0, x, L); add_opening(0, x + B, L); add_opening(0, x + 2 * B, L); add_opening(1, x, L);   // prover.rs:266-277
+    for (uint32_t i = 0; i < rho0; ++i) {                                                                   // prover.rs:280-289
+        const size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
+        add_opening(1 + i, xi, L - i);
+        add_opening(1 + i, nx, L - i);
+    }
+    const size_t nv = vit.size(), nd = dit.size(), row = nv + 8 * nd;
+    if (nv + nd > s->gather_slots || row > s->gather_words) return fail(ZK_ERR_STATE, "zk_shard: gather capacity exceeded");
+    for (size_t i = 0; i < nv; ++i) s->h_goff[i] = vit[i].owner == me ? vit[i].off : 0;
+    for (size_t i = 0; i < nd; ++i) s->h_goff[nv + i] = dit[i].owner == me ? dit[i].off : 0;
+    int rc;
+    HIPCHK(hipMemcpyAsync(s->d_goff, s->h_goff, (nv + nd) * 8, hipMemcpyHostToDevice, s->stream));
+    if ((rc = zk_dev_gather(s->d_layers, s->d_goff, (uint32_t)nv, 1, s->d_gout, s->stream))) return rc;
+    if ((rc = zk_dev_gather(s->d_trees, s->d_goff + nv, (uint32_t)nd, 8, s->d_gout + nv, s->stream))) return rc;
+    if (collectives(s)) {
+        if ((rc = all_gather(s, s->d_gout, s->d_gall, row, s->stream))) return rc;
+        HIPCHK(hipMemcpyAsync(s->h_gall, s->d_gall, row * 4 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(s->h_gall, s->d_gout, row * 4, hipMemcpyDeviceToHost, s->stream));
+    }
+    // the tail layers' openings come from the replicated tail (every rank has them)
+    std::vector<uint32_t> tvals(2 * (size_t)s->tail_rounds + 1);
+    size_t tdig = 0;
+    for (uint32_t j = 0; j < s->tail_rounds; ++j) tdig += 2 * (size_t)(L - rho0 - j);
+    std::vector<uint8_t> tpaths(32 * tdig + 1);
+    if ((rc = zk_tail_open(s->tail, x, tvals.data(), tpaths.data()))) return rc;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    auto val_of = [&](size_t i) { return s->h_gall[(size_t)vit[i].owner * row * (collectives(s) ? 1 : 0) + i]; };
+    std::vector<uint8_t> path;
+    size_t dpos = 0;
+    auto path_of = [&](size_t k) -> const uint8_t* {          // opening k: local digests from their owner's row, then the top path
+        const Open& o = opens[k];
+        path.resize(32 * (o.nloc + s->lg));
+        for (size_t i = 0; i < o.nloc; ++i) {
+            const size_t r = collectives(s) ? (size_t)dit[dpos + i].owner : 0;
+            digest_words_to_bytes(s->h_gall + r * row + nv + 8 * (dpos + i), path.data() + 32 * i);
+        }
+        dpos += o.nloc;
+        nodes.clear();
+        if (G > 1) path_nodes((size_t)G, o.block, nodes);
+        for (size_t i = 0; i < nodes.size(); ++i) digest_words_to_bytes(s->tops[o.lid].data() + nodes[i] * 8, path.data() + 32 * (o.nloc + i));
+        return path.data();
+    };
+    for (size_t k = 0; k < 4; ++k) {                          // prover.rs:274-277
+        const uint8_t* p = path_of(k);
+        ch.commit_val_path(val_of(k), p, L);
+    }
+    std::vector<uint8_t> p0;
+    for (uint32_t i = 0; i < rho0; ++i) {                     // prover.rs:288
+        const size_t pl = L - i;
+        const uint8_t* a = path_of(4 + 2 * i);
+        p0.assign(a, a + 32 * pl);
+        const uint8_t* b = path_of(5 + 2 * i);
+        ch.commit_pair_paths(val_of(4 + 2 * i), val_of(5 + 2 * i), p0.data(), b, pl);
+    }
+    size_t tp = 0;
+    for (uint32_t j = 0; j < s->tail_rounds; ++j) {           // the replicated layers, from zk_tail_open
+        const size_t pl = L - rho0 - j;
+        ch.commit_pair_paths(tvals[2 * j], tvals[2 * j + 1], tpaths.data() + 32 * tp, tpaths.data() + 32 * (tp + pl), pl);
+        tp += 2 * pl;
+    }
+    return ZK_OK;
+}
+
+int prove(zk_shard* s, Channel& ch) {
+    if (!s->have_trace) return fail(ZK_ERR_STATE, "zk_shard_prove: no trace uploaded");
+    const uint32_t L = s->L, R = s->R, lg = s->lg, rho0 = s->n_sharded;
+    int rc;
+    uint8_t root[32];
+    memset(&s->info, 0, sizeof s->info);
+    s->info.public_last = s->last;
+    s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
+    s->stats.chunked_layers = 0;
+    ch.data.reserve(ch.data.size() + proof_data_len(s->log_n, s->log_b));
+    if ((rc = do_lde(s))) return rc;                                              // prover.rs:60-70
+    if ((rc = commit_sharded(s, 0, L, root))) return rc;                           // prover.rs:81
+    ch.commit_hash(root);                                                          // prover.rs:85
+    memcpy(s->info.roots[0], root, 32);
+    uint32_t alpha[3];
+    for (int i = 0; i < 3; ++i) alpha[i] = s->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
+    if ((rc = zk_dev_compose(s->dom_loc, layer_ptr(s, 0), layer_ptr(s, 1), s->first, s->last, alpha, s->stream))) return rc;   // :166-173
+    if ((rc = commit_sharded(s, 1, L, root))) return rc;                           // prover.rs:176
+    ch.commit_hash(root);                                                          // prover.rs:180
+    memcpy(s->info.roots[1], root, 32);
+    uint32_t free_term = 0;
+    for (uint32_t rho = 0; rho < rho0; ++rho) {                                    // prover.rs:198-225, the distributed rounds
+        const uint32_t beta = s->info.beta_raw[rho] = ch.get_u32();                // prover.rs:200
+        const uint32_t m_log = L - rho;
+        if (rho + 1 < rho0) {
+            if ((rc = zk_dev_fri_fold(s->dom_loc, layer_ptr(s, 1 + rho), layer_ptr(s, 2 + rho), m_log - lg, rho, beta, s->stream))) return rc;
+            if ((rc = commit_sharded(s, 2 + rho, m_log - 1, root))) return rc;
+            ch.commit_hash(root);                                                  // prover.rs:224
+            memcpy(s->info.roots[2 + rho], root, 32);
+            continue;
+        }
+        // replication switch: fold locally, all-gather the G cyclic pieces, interleave to natural order, then the
+        // commitment of that layer and every later round in one call on every rank (zk_tail_run)
+        const size_t cnt = ((size_t)1 << (m_log - 1)) >> lg;
+        uint32_t* piece = s->d_recv;
+        if ((rc = zk_dev_fri_fold(s->dom_loc, layer_ptr(s, 1 + rho), piece, m_log - lg, rho, beta, s->stream))) return rc;
+        const uint32_t* handed = piece;
+        if (collectives(s)) {
+            if ((rc = all_gather(s, piece, s->d_gbuf, cnt, s->stream))) return rc;
+            if ((rc = zk_dev_interleave(s->d_gbuf, s->d_repl, lg, m_log - 1 - lg, s->stream))) return rc;
+            handed = s->d_repl;
+        }
+        zk_channel chan_view;                                                      // zk_tail_run drives the caller's channel
+        chan_view.ch = std::move(ch);
+        std::vector<uint8_t> troots(32 * ((size_t)s->tail_rounds + 1));
+        rc = zk_tail_run(s->tail, handed, s->stream, &chan_view, ZK_HASH_SHA256, s->info.beta_raw + rho0, troots.data(), &free_term);
+        ch = std::move(chan_view.ch);
+        if (rc) return rc;
+        for (uint32_t j = 0; j <= s->tail_rounds; ++j) memcpy(s->info.roots[1 + rho0 + j], troots.data() + 32 * j, 32);
+    }
+    (void)R;
+    s->info.free_term = free_term;
+    ch.commit_u32(free_term);                                                      // prover.rs:254
+    const uint32_t qraw = s->info.query_raw = ch.get_u32();                        // prover.rs:263
+    return decommit(s, ch, (size_t)qraw % (s->N - 2 * s->B));
+}
+
+template <typename T>
+int dalloc(zk_shard* s, T** p, size_t bytes) {
+    hipError_t e = hipMalloc((void**)p, bytes ? bytes : 4);
+    if (e != hipSuccess) return fail(ZK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    s->device_bytes += (double)bytes;
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]) {
+    if (!id_out) return fail(ZK_ERR_INVALID, "zk_shard_unique_id: null argument");
+    const RcclApi* api = rccl_api();
+    if (!api) return ZK_ERR_STATE;
+    static_assert(sizeof(ncclUniqueId) == ZK_SHARD_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(ZK_ERR_HIP, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    memcpy(id_out, &id, ZK_SHARD_ID_BYTES);
+    return ZK_OK;
+}
+
+int zk_shard_destroy(zk_shard* s) {
+    if (!s) return ZK_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->xstream) (void)hipStreamSynchronize(s->xstream);
+    if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
+    s->board.close();
+    if (s->tail) zk_ctx_destroy(s->tail);
+    if (s->committer) zk_committer_destroy(s->committer);
+    if (s->dom_loc) zk_dom_destroy(s->dom_loc);
+    for (void* p : {(void*)s->d_trace, (void*)s->d_coef, (void*)s->d_layers, (void*)s->d_trees, (void*)s->d_recv, (void*)s->d_gbuf,
+                    (void*)s->d_repl, (void*)s->d_small, (void*)s->d_goff, (void*)s->d_gout, (void*)s->d_gall})
+        if (p) (void)hipFree(p);
+    for (void* p : {(void*)s->h_goff, (void*)s->h_gall, (void*)s->h_small})
+        if (p) (void)hipHostFree(p);
+    if (s->ev_layer) (void)hipEventDestroy(s->ev_layer);
+    for (hipEvent_t e : s->ev_chunk) if (e) (void)hipEventDestroy(e);
+    if (s->xstream) (void)hipStreamDestroy(s->xstream);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return ZK_OK;
+}
+
+int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk_shard_transport* transport, const zk_shard_options* opt,
+                    uint32_t log_n, uint32_t log_b, zk_shard** out) {
+    if (!out) return fail(ZK_ERR_INVALID, "zk_shard_create: out is null");
+    *out = nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    if (int rc = check_proof_size("zk_shard_create", log_n, log_b)) return rc;
+    uint32_t lg = 0;
+    while ((1 << lg) < world) ++lg;
+    if (world < 1 || world > 32 || (1 << lg) != world || lg > log_b || rank < 0 || rank >= world)
+        return fail(ZK_ERR_INVALID, "zk_shard_create: world size %d must be a power of two dividing the blow-up %u, 0 <= rank < world", world, 1u << log_b);
+    if (transport && (!transport->all_to_all || !transport->all_gather)) return fail(ZK_ERR_INVALID, "zk_shard_create: incomplete transport");
+    if (!transport && !id) return fail(ZK_ERR_INVALID, "zk_shard_create: the RCCL transport needs the shared unique id (zk_shard_unique_id)");
+    HIPCHK(hipSetDevice(device));
+    zk_shard* s = new (std::nothrow) zk_shard();
+    if (!s) return fail(ZK_ERR_NOMEM, "out of host memory");
+    s->device = device; s->rank = rank; s->G = world; s->lg = lg;
+    s->log_n = log_n; s->log_b = log_b; s->L = log_n + log_b; s->R = log_n;
+    s->n = (size_t)1 << log_n; s->B = (size_t)1 << log_b; s->N = s->n << log_b;
+    if (opt) {
+        if (opt->min_layer_log) s->min_layer_log = opt->min_layer_log;
+        if (opt->min_chunk_log) s->min_chunk_log = opt->min_chunk_log;
+        if (opt->overlap_min_log) s->overlap_min_log = opt->overlap_min_log;
+        s->force = opt->force_collectives != 0;
+    }
+    if (getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1) s->overlap_min_log = 99;   // operational switch: plain collectives only
+    int rc = ZK_OK;
+    auto bail = [&](int code) { zk_shard_destroy(s); return code; };
+#define HIPCHK_S(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            zk_shard_destroy(s);                                                              \
+            return fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                     \
+    } while (0)
+    const uint32_t L = s->L, R = s->R;
+    if (L < 2 * lg + s->min_chunk_log) return bail(fail(ZK_ERR_INVALID, "zk_shard_create: domain 2^%u is too small to shard over %d ranks: use zk_prove", L, world));
+    // FRI layer rho (2^(L-rho) values) stays distributed while it has >= 2^min_layer_log values and a (rank, peer)
+    // piece has >= 2^min_chunk_log leaves; layer 0 (cp) is always distributed, like f; at least one round is left
+    // to the replicated tail (the last layers are tiny)
+    uint32_t ns = 0;
+    for (uint32_t rho = 0; rho <= R; ++rho)
+        if (L - rho >= s->min_layer_log && L - rho >= 2 * lg + s->min_chunk_log) ++ns;
+    if (ns < 1) ns = 1;
+    if (ns > R - 1) ns = R - 1;
+    s->n_sharded = ns;
+    s->tail_rounds = R - ns;
+    HIPCHK_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCHK_S(hipStreamCreateWithFlags(&s->xstream, hipStreamNonBlocking));
+    HIPCHK_S(hipEventCreateWithFlags(&s->ev_layer, hipEventDisableTiming));
+    for (hipEvent_t& e : s->ev_chunk) HIPCHK_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // transport
+    if (transport) {
+        s->tp = *transport;
+    } else {
+        s->rccl = rccl_api();
+        if (!s->rccl) return bail(ZK_ERR_STATE);
+        ncclUniqueId nid;
+        memcpy(&nid, id, sizeof nid);
+        ncclResult_t r = s->rccl->CommInitRank(&s->comm, world, nid, rank);
+        if (r != ncclSuccess) { s->comm = nullptr; return bail(fail(ZK_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, s->rccl->GetErrorString(r))); }
+        s->tp.user = s;
+        s->tp.all_to_all = rccl_all_to_all;
+        s->tp.all_gather = rccl_all_gather;
+        s->stats.native_rccl = 1;
+    }
+    // this rank's coset: shift w h^rank, blow-up B/G; the replicated tail: layer ns of the proof is layer 0 of the
+    // domain with n' = n >> ns and shift w^(2^ns)
+    const uint32_t h = root_of_unity(L);
+    const uint32_t shift = mulmod(GEN_W, powmod(h, (uint64_t)rank));
+    if ((rc = zk_dom_create(device, log_n, log_b - lg, shift, 0, &s->dom_loc))) return bail(rc);
+    if ((rc = zk_tail_create(device, s->tail_rounds, log_b, powmod(GEN_W, (uint64_t)1 << ns), &s->tail))) return bail(rc);
+    if ((rc = zk_committer_create(device, &s->committer))) return bail(rc);
+    // layers: 0 = f, 1 + rho = FRI layer rho < ns (distributed); one allocation for layers, one for trees
+    const size_t NL = s->N >> lg;
+    size_t off = 0;
+    for (uint32_t lid = 0; lid <= ns; ++lid) {
+        const size_t len = lid == 0 ? NL : ((s->N >> (lid - 1)) >> lg);
+        s->layer_off.push_back(off); s->layer_len.push_back(len); off += len;
+    }
+    const size_t layer_words = off;
+    off = 0;
+    for (uint32_t t = 0; t <= ns; ++t) { s->tree_off.push_back(off); s->tree_leaves.push_back(s->layer_len[t]); off += (2 * s->layer_len[t] - 1) * 8; }
+    const size_t tree_words = off;
+    const size_t repl = s->N >> ns;                            // the first replicated layer
+    s->gather_slots = (size_t)(4 + 2 * ns) * (L + 1) + 64;
+    s->gather_words = (size_t)(4 + 2 * ns) * (1 + 8 * (size_t)L) + 64;
+    if ((rc = dalloc(s, &s->d_trace, s->n * 4)) || (rc = dalloc(s, &s->d_coef, 2 * s->n * 4)) || (rc = dalloc(s, &s->d_layers, layer_words * 4)) ||
+        (rc = dalloc(s, &s->d_trees, tree_words * 4)) || (rc = dalloc(s, &s->d_recv, NL * 4)) || (rc = dalloc(s, &s->d_gbuf, repl * 4)) ||
+        (rc = dalloc(s, &s->d_repl, repl * 4)) || (rc = dalloc(s, &s->d_small, 4096)) || (rc = dalloc(s, &s->d_goff, s->gather_slots * 8)) ||
+        (rc = dalloc(s, &s->d_gout, s->gather_words * 4)) || (rc = dalloc(s, &s->d_gall, s->gather_words * 4 * (size_t)world)))
+        return bail(rc);
+    HIPCHK_S(hipHostMalloc((void**)&s->h_goff, s->gather_slots * 8));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_gall, s->gather_words * 4 * (size_t)world));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_small, 4096));
+    s->tops.resize(ns + 1);
+    s->device_bytes += (double)zk_ctx_device_bytes(s->tail);
+    // subtree roots through shared memory when every rank can map the object (one node); else the all-gather
+    if (collectives(s) && id && !(opt && opt->no_root_board) && !(getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1)) {
+        uint8_t dg[32];
+        Sha256 hsh; hsh.update(id, ZK_SHARD_ID_BYTES); hsh.finalize(dg);
+        char name[64];
+        snprintf(name, sizeof name, "/zkstark_amd_%02x%02x%02x%02x%02x%02x%02x%02x", dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], dg[6], dg[7]);
+        bool ok = true, all = false;
+        if (rank == 0) ok = s->board.open_or_create(name, rank, world, true);
+        if ((rc = agree(s, ok, &all))) return bail(rc);        // the object exists (or rank 0 failed) before anybody opens it
+        if (all && rank != 0) ok = s->board.open_or_create(name, rank, world, false);
+        bool mapped = false;
+        if ((rc = agree(s, all && ok, &mapped))) return bail(rc);   // everybody has mapped it: the name can go
+        if (rank == 0) shm_unlink(name);
+        s->use_board = mapped;
+        if (!mapped) s->board.close();
+    }
+    HIPCHK_S(hipStreamSynchronize(s->stream));
+#undef HIPCHK_S
+    s->stats.sharded_layers = ns;
+    s->stats.root_board = s->use_board ? 1 : 0;
+    s->stats.device_bytes = s->device_bytes;
+    s->stats.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = s;
+    return ZK_OK;
+}
+
+int zk_shard_trace_upload(zk_shard* s, const uint32_t* trace, size_t count) {
+    if (!s || !trace) return fail(ZK_ERR_INVALID, "zk_shard_trace_upload: null argument");
+    if (count != s->n - 1) return fail(ZK_ERR_INVALID, "zk_shard_trace_upload: expected n-1 = %zu values, got %zu", s->n - 1, count);
+    for (size_t i = 0; i < count; ++i)
+        if (trace[i] >= P) return fail(ZK_ERR_INVALID, "zk_shard_trace_upload: trace[%zu] = %u is not a canonical residue", i, trace[i]);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpyAsync(s->d_trace, trace, count * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_trace + count, 0, 4, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->first = trace[0];
+    s->last = trace[count - 1];
+    s->have_trace = true;
+    return ZK_OK;
+}
+
+int zk_shard_prove_channel(zk_shard* s, zk_channel* chan) {
+    if (!s || !chan) return fail(ZK_ERR_INVALID, "zk_shard_prove_channel: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    return prove(s, chan->ch);
+}
+
+int zk_shard_prove(zk_shard* s, uint8_t* proof_out, size_t cap, size_t* proof_len, uint8_t state_out[32]) {
+    if (!s || !proof_out || !state_out) return fail(ZK_ERR_INVALID, "zk_shard_prove: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    Channel ch;                                                // main.rs:19
+    int rc = prove(s, ch);
+    if (rc) return rc;
+    if (proof_len) *proof_len = ch.data.size();
+    if (ch.data.size() > cap) return fail(ZK_ERR_BUFFER, "zk_shard_prove: proof needs %zu bytes, buffer has %zu", ch.data.size(), cap);
+    memcpy(proof_out, ch.data.data(), ch.data.size());         // channel.rs:34-36
+    memcpy(state_out, ch.state, 32);
+    return ZK_OK;
+}
+
+int zk_shard_lde_commit(zk_shard* s, uint8_t root_out[32]) {
+    if (!s || !root_out) return fail(ZK_ERR_INVALID, "zk_shard_lde_commit: null argument");
+    if (!s->have_trace) return fail(ZK_ERR_STATE, "zk_shard_lde_commit: no trace uploaded");
+    HIPCHK(hipSetDevice(s->device));
+    s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
+    s->stats.chunked_layers = 0;
+    int rc = do_lde(s);                                         // prover.rs:60-70, each rank its cosets
+    if (!rc) rc = commit_sharded(s, 0, s->L, root_out);         // the all-to-all transpose + prover.rs:81
+    return rc;
+}
+
+int zk_shard_last_transcript(const zk_shard* s, zk_transcript_info* out) {
+    if (!s || !out) return fail(ZK_ERR_INVALID, "zk_shard_last_transcript: null argument");
+    *out = s->info;
+    return ZK_OK;
+}
+
+int zk_shard_layer_read(zk_shard* s, uint32_t layer, size_t offset, size_t count, uint32_t* out) {
+    if (!s || (!out && count)) return fail(ZK_ERR_INVALID, "zk_shard_layer_read: null argument");
+    if (layer > s->n_sharded || offset + count > s->layer_len[layer]) return fail(ZK_ERR_INVALID, "zk_shard_layer_read: out of range");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpyAsync(out, layer_ptr(s, layer) + offset, count * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return ZK_OK;
+}
+
+int zk_shard_get_stats(const zk_shard* s, zk_shard_stats* out) {
+    if (!s || !out) return fail(ZK_ERR_INVALID, "zk_shard_get_stats: null argument");
+    *out = s->stats;
+    return ZK_OK;
+}
+
+}  // extern "C"

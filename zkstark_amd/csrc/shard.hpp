@@ -1,0 +1,17 @@
+// shard.hpp -- internals of the sharded prover (shard.hip): one proof across the GPUs of a node.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "internal.hpp"
+
+namespace zk {
+namespace impl {
+
+// RCCL, loaded at run time (librccl.so.1): a process that never shards needs no RCCL, and a process that has
+// PyTorch loaded gets PyTorch's copy (same SONAME), i.e. the one that matches the HIP runtime already in use.
+struct RcclApi;
+const RcclApi* rccl_api();                 // nullptr + fail() recorded when the library cannot be loaded
+
+}  // namespace impl
+}  // namespace zk

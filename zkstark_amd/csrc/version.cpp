@@ -1,0 +1,12 @@
+// version.cpp -- the only translation unit that sees the source hash (build.py passes -DZK_SRC_HASH), so an
+// edit anywhere else recompiles that file and this stub, not the whole library.
+#include "../../include/zkstark_amd.h"
+
+#ifndef ZK_SRC_HASH
+#define ZK_SRC_HASH "unknown"
+#endif
+
+extern "C" {
+const char* zk_version(void) { return "zkstark_amd 0.2 (gfx950)"; }
+const char* zk_build_hash(void) { return ZK_SRC_HASH; }
+}

@@ -291,7 +291,9 @@ int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
 }
 
 
-int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]) {
+// generate_proof(channel) (prover.rs:9): everything is committed to, and every challenge drawn from, the
+// caller's channel `ch`, which may already hold a transcript prefix (main.rs:19 starts from a fresh one).
+int prove_resident(zk_ctx* c, Channel& ch) {
     if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_prove_resident: no trace uploaded");
     static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
@@ -303,8 +305,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
     };
     const uint32_t R = c->R;
     const size_t B = c->B, N = c->N;
-    Channel ch;                                          // main.rs:19
-    ch.data.reserve(proof_data_len(c->log_n, c->log_b, c->queries));
+    ch.data.reserve(ch.data.size() + proof_data_len(c->log_n, c->log_b, c->queries));
     uint8_t root[32];
     int rc;
     memset(&c->info, 0, sizeof c->info);
@@ -390,9 +391,7 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
         }
     }
     lap("decommit host hashing");
-    proof = std::move(ch.data);                           // channel.rs:34-36
-    memcpy(state_out, ch.state, 32);
-    return ZK_OK;
+    return ZK_OK;                                         // the proof is the channel: channel.rs:34-36
 }
 
 }  // namespace
@@ -403,7 +402,6 @@ int prove_resident(zk_ctx* c, std::vector<uint8_t>& proof, uint8_t state_out[32]
 extern "C" {
 
 const char* zk_last_error(void) { return last_error(); }
-const char* zk_version(void) { return "zkstark_amd 0.1 (gfx950)"; }
 
 uint32_t zk_field_add(uint32_t a, uint32_t b) { return add(a % P, b % P); }
 uint32_t zk_field_sub(uint32_t a, uint32_t b) { return sub(a % P, b % P); }
@@ -429,10 +427,7 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
 int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     if (!out) return fail(ZK_ERR_INVALID, "zk_ctx_create: out is null");
     *out = nullptr;
-    if (log_n < 2 || log_b < 1 || log_b > 5 || log_n + log_b > 30)
-        return fail(ZK_ERR_INVALID, "zk_ctx_create: need 2 <= log_n, 1 <= log_blowup <= 5, log_n + log_blowup <= 30 (got %u, %u)", log_n, log_b);
-    if (log_n == 3)   // g^4 = -1: the leading terms of f(gx)^2 + f(x)^2 cancel and deg c2 < n-1
-        return fail(ZK_ERR_INVALID, "zk_ctx_create: n = 8 is degenerate for the Fibonacci-square constraints (the degree asserts of prover.rs:156/:169 would fail)");
+    if (int rc = check_proof_size("zk_ctx_create", log_n, log_b)) return rc;
     return ctx_make(device, log_n, log_b, GEN_W, false, out);
 }
 
@@ -692,15 +687,24 @@ int zk_merkle_path(zk_ctx* c, uint32_t tree, size_t leaf, uint8_t* out, size_t* 
 int zk_prove_resident(zk_ctx* c, uint8_t* proof_out, size_t cap, size_t* proof_len, uint8_t state_out[32]) {
     if (!c || !proof_out || !state_out) return fail(ZK_ERR_INVALID, "zk_prove_resident: null argument");
     HIPCHK(hipSetDevice(c->device));
-    std::vector<uint8_t> proof;
-    uint8_t st[32];
-    int rc = prove_resident(c, proof, st);
+    Channel ch;                                           // main.rs:19
+    int rc = prove_resident(c, ch);
     if (rc) return rc;
+    const std::vector<uint8_t>& proof = ch.data;          // channel.rs:34-36
     if (proof_len) *proof_len = proof.size();
     if (proof.size() > cap) return fail(ZK_ERR_BUFFER, "zk_prove: proof needs %zu bytes, buffer has %zu", proof.size(), cap);
     memcpy(proof_out, proof.data(), proof.size());
-    memcpy(state_out, st, 32);
+    memcpy(state_out, ch.state, 32);
     return ZK_OK;
+}
+
+// generate_proof(channel: Channel) -> Proof (prover.rs:9): the literal drop-in.  The resident trace is proved on the
+// caller's channel: every commitment is appended to it and every challenge drawn from it, whatever it already holds.
+int zk_prove_channel(zk_ctx* c, zk_channel* chan) {
+    if (!c || !chan) return fail(ZK_ERR_INVALID, "zk_prove_channel: null argument");
+    if (c->tail) return fail(ZK_ERR_STATE, "zk_prove_channel: FRI-tail context");
+    HIPCHK(hipSetDevice(c->device));
+    return prove_resident(c, chan->ch);
 }
 
 int zk_prove(zk_ctx* c, const uint32_t* trace, size_t count, uint8_t* proof_out, size_t cap, size_t* proof_len,
@@ -786,9 +790,6 @@ int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t* pat
 }
 
 // ---- Channel -------------------------------------------------------------------
-struct zk_channel {
-    Channel ch;
-};
 
 // ---- FRI tail -----------------------------------------------------------------------
 // The last FRI layers of a proof whose earlier layers live elsewhere (the sharded prover hands
@@ -868,6 +869,14 @@ int zk_channel_new(zk_channel** out) {
     return *out ? ZK_OK : fail(ZK_ERR_NOMEM, "out of host memory");
 }
 int zk_channel_free(zk_channel* ch) { delete ch; return ZK_OK; }
+// Adopts the two fields of a Channel kept elsewhere (channel.rs:6-9): the caller's Rust Channel crosses the FFI as
+// (state, data) and comes back through zk_channel_state / zk_channel_data.
+int zk_channel_import(zk_channel* ch, const uint8_t state[32], const uint8_t* data, size_t n) {
+    if (!ch || !state || (!data && n)) return fail(ZK_ERR_INVALID, "null argument");
+    memcpy(ch->ch.state, state, 32);
+    ch->ch.data.assign(data, data + n);
+    return ZK_OK;
+}
 int zk_channel_commit(zk_channel* ch, const uint8_t* bytes, size_t n) {
     if (!ch || (!bytes && n)) return fail(ZK_ERR_INVALID, "null argument");
     ch->ch.commit_bytes(bytes, n);
@@ -994,11 +1003,16 @@ struct zk_committer {
     uint32_t* h_stage = nullptr;    // pinned, mapped: host-built top nodes, then one ScatterSeg
     uint32_t* d_stage = nullptr;
     uint32_t seq = 0, top = 0;
+    // h_stage is read by the scatter launch of the previous commit, which may sit on ANY stream the caller passed:
+    // its completion is awaited (an event, normally long signalled) before the next commit overwrites the buffer
+    hipEvent_t stage_free = nullptr;
+    bool stage_busy = false;
 };
 int zk_committer_destroy(zk_committer* k) {
     if (!k) return ZK_OK;
     (void)hipSetDevice(k->device);
     (void)hipDeviceSynchronize();                      // a scatter launch may still read the staging buffer
+    if (k->stage_free) (void)hipEventDestroy(k->stage_free);
     if (k->h_mail) (void)hipHostFree(k->h_mail);
     if (k->h_stage) (void)hipHostFree(k->h_stage);
     if (k->d_counter) (void)hipFree(k->d_counter);
@@ -1019,6 +1033,7 @@ int zk_committer_create(int device, zk_committer** out) {
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&k->d_stage, k->h_stage, 0);
     if (e == hipSuccess) e = hipMalloc((void**)&k->d_counter, 64);
     if (e == hipSuccess) e = hipMemset(k->d_counter, 0, 64);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&k->stage_free, hipEventDisableTiming);
     if (e != hipSuccess) { zk_committer_destroy(k); return fail(ZK_ERR_HIP, "zk_committer_create: %s", hipGetErrorString(e)); }
     memset(k->h_mail, 0, kMailValsOff * 4);
     k->top = host_sha_available() ? 8 : 0;
@@ -1034,6 +1049,7 @@ static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nod
     if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
     const size_t cnt = (size_t)1 << m.top;
     uint32_t* nodes = k->h_stage;
+    if (k->stage_busy) { HIPCHK(hipEventSynchronize(k->stage_free)); k->stage_busy = false; }   // previous scatter done with h_stage
     memcpy(nodes + 8 * (cnt - 1), k->h_mail + kMailDigests, cnt * 32);
     host_sha_reduce(nodes, m.top);
     digest_words_to_bytes(nodes, root_out);
@@ -1041,6 +1057,8 @@ static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nod
     *seg = ScatterSeg{0, 0, (uint32_t)((cnt - 1) * 8), 0};
     HIPCHK(launch_scatter(k->d_stage, reinterpret_cast<ScatterSeg*>(k->d_stage + ((size_t)16 << kMaxHostLog)), 1, (double)seg->words,
                           d_nodes, nullptr, s, dev_prof()));
+    HIPCHK(hipEventRecord(k->stage_free, s));
+    k->stage_busy = true;
     return ZK_OK;
 }
 

@@ -301,6 +301,15 @@ class Context:
         info = self.last_transcript()
         return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, info.public_last, self.hash, self.queries)
 
+    def prove_channel(self, channel):
+        """generate_proof(channel) (prover.rs:9) in one C call on the caller's Channel (zk_prove_channel): the
+        resident trace is proved on top of whatever the channel already holds; returns channel.finalize(...)."""
+        check(_lib.load().zk_prove_channel(self._h, channel._h))
+        return channel.finalize(self.log_n, self.log_blowup, self.last_transcript().public_last)
+
+    def set_host_levels(self, top_log, tail_log):
+        check(_lib.load().zk_ctx_set_host_levels(self._h, top_log, tail_log))
+
     def last_transcript(self):
         info = _lib.TranscriptInfo()
         check(_lib.load().zk_last_transcript(self._h, C.byref(info)))
@@ -384,6 +393,73 @@ class BatchContext:
         last = self.public_last()
         return [Proof(states[p].tobytes(), data[p].tobytes(), self.log_n, self.log_blowup, int(last[p]), self.hash, self.queries)
                 for p in range(self.batch)]
+
+
+def shard_unique_id():
+    """ncclGetUniqueId (rank 0): the 128 bytes every rank hands to ShardContext."""
+    buf = C.create_string_buffer(128)
+    check(_lib.load().zk_shard_unique_id(buf))
+    return buf.raw
+
+
+class ShardContext:
+    """One proof sharded over `world` GPUs (zk_shard_*): this process is rank `rank`.  Collective: every rank
+    constructs it and calls the same methods in the same order.  transport=None uses RCCL (native, inside the
+    library) with the shared `unique_id`; a _lib.ShardTransport supplies the caller's own collectives."""
+
+    def __init__(self, log_n, log_blowup, rank, world, unique_id=None, device=0, transport=None, min_layer_log=0, min_chunk_log=0,
+                 overlap_min_log=0, force_collectives=False, no_root_board=False):
+        self.log_n, self.log_blowup, self.rank, self.world = log_n, log_blowup, rank, world
+        self._transport = transport                      # keeps the callbacks alive
+        opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), int(no_root_board))
+        self._h = C.c_void_p()
+        idb = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        check(_lib.load().zk_shard_create(device, rank, world, idb, C.byref(transport) if transport is not None else None,
+                                          C.byref(opt), log_n, log_blowup, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().zk_shard_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def trace_upload(self, trace):
+        t = _u32arr(trace)
+        check(_lib.load().zk_shard_trace_upload(self._h, _ptr(t), len(t)))
+
+    def prove(self):
+        cap = _lib.load().zk_proof_data_len(self.log_n, self.log_blowup)
+        buf, st, n = C.create_string_buffer(cap), C.create_string_buffer(32), C.c_size_t()
+        check(_lib.load().zk_shard_prove(self._h, buf, cap, C.byref(n), st))
+        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, self.last_transcript().public_last)
+
+    def prove_channel(self, channel):
+        check(_lib.load().zk_shard_prove_channel(self._h, channel._h))
+        return channel.finalize(self.log_n, self.log_blowup, self.last_transcript().public_last)
+
+    def lde_commit(self):
+        out = C.create_string_buffer(32)
+        check(_lib.load().zk_shard_lde_commit(self._h, out))
+        return out.raw
+
+    def last_transcript(self):
+        info = _lib.TranscriptInfo()
+        check(_lib.load().zk_shard_last_transcript(self._h, C.byref(info)))
+        return info
+
+    def layer_read(self, layer, offset, count):
+        out = np.zeros(count, dtype=np.uint32)
+        check(_lib.load().zk_shard_layer_read(self._h, layer, offset, count, _ptr(out)))
+        return out
+
+    def stats(self):
+        st = _lib.ShardStats()
+        check(_lib.load().zk_shard_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.ShardStats._fields_}
 
 
 def generate_proof(channel, log_n=10, log_blowup=3, a0=1, a1=3141592, ctx=None):
