@@ -5,18 +5,25 @@ Metric (BASELINE.json): field-elements/s through LDE + Merkle + FRI = N / t, N =
 domain size, t = wall time from "trace values resident on the device" to "proof bytes on the
 host" (context / twiddle setup excluded, reported separately).  Default workload: the full
 prover at domain 2^24 (BASELINE.json configs[2]; trace group 2^21, blow-up 8) on synthetic
-Fibonacci-square traces.
+Fibonacci-square traces.  With --gpus N > 1: ONE proof at domain 2^24 * N sharded over the N
+GPUs (weak scaling) by the native sharded prover (zk_shard_*: RCCL all-to-all per commitment).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 21] [--log-blowup 3]
 
+`--gpus N` without a launcher starts the N ranks itself (one child process per GPU, before anything
+touches the GPU); under `torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
+
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel
-(merkle_subtree_kernel<leaf>), timed live with HIP events on the context stream inside the
+(merkle_subtree_kernel<leaf>), timed live with HIP events on the launch stream inside the
 timed region; `cpu_baseline` is the CPU oracle (oracle/, a port of the reference algorithm
-with O(N log N) transforms) on a bounded sample, rank 0 at N=1 only.
+with O(N log N) transforms) on a bounded sample, rank 0 at N=1 only; `parity_checked` says the
+timed proof's bytes were compared with the oracle's proof of the same trace.
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -25,38 +32,85 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-# 32-bit VALU: 64 lanes/clk/CU measured for every op SHA-256 uses (tools/valu_microbench.hip):
-# 256 CUs x 64 lanes x 2.4 GHz = 39.3 T lane-ops/s nominal; 35 T measured at the clock the chip holds.
+# 32-bit VALU: 64 lanes/clk/CU measured for every op SHA-256 uses, at 1/2/4/8 waves per SIMD
+# (tools/valu_microbench.hip, profiles/r02_valu_microbench.txt): 256 CUs x 64 lanes x 2.4 GHz = 39.3 T lane-ops/s.
 VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
-PROFILE_VALU = os.path.join(ROOT, "profiles", "valu_utilization.json")   # PMC-derived VALU issue utilisation
+SHA_LEAF_OPS, SHA_INNER_OPS = 1259, 2293
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (stamped with its commit)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=21, help="log2 of the trace group size n")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log-n", type=int, default=21, help="log2 of the trace group size n (per GPU)")
     ap.add_argument("--log-blowup", type=int, default=3)
     ap.add_argument("--hash", choices=("sha256", "field"), default="sha256",
                     help="Merkle hash: the reference's SHA-256 (the benchmark), or the field-native hash of configs[4]")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary figures (configs[1] and proofs in flight): profiling runs")
+                    help="skip the secondary figures (configs[1], proofs in flight, batches, staged stages): profiling runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="also report throughput with this many proofs in flight (1 = skip)")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=21, help="oracle sample: domain 2^(this+blowup)")
+    ap.add_argument("--soak-seconds", type=float, default=3.0,
+                    help="after the timed region: keep proving for this long (untimed by the metric; steady-state figure)")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=None, help="oracle sample: domain 2^(this+blowup); default: the benchmark's own size")
+    ap.add_argument("--plain-collectives", action="store_true", help="N > 1: no chunked exchange, no shared-memory root board")
+    ap.add_argument("--staged-only", action="store_true", help="run only the stage-by-stage leg (rocprofv3 of compose / fold kernels)")
     return ap.parse_args()
 
 
+# ---- N > 1 without a launcher: one child per GPU, started before this process touches torch or the GPU ----------
+def spawn_ranks(args):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 inherits stdout (the one JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(args.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in live:
+                    procs[q].terminate()                   # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+def host_cores():
+    """Cores this process may use: the affinity mask (what `nproc` prints), capped by a cgroup CPU quota."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = max(1, math.ceil(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return (min(aff, quota) if quota else aff), aff, quota
+
+
 def cpu_baseline(sample_log_n, log_b):
-    """Times the CPU oracle (kind 'port': the reference is a Rust crate that cannot be built
-    here) on a bounded sample of the same workload: the full prover at a smaller domain."""
+    """Times the CPU oracle (kind 'port': the reference is a Rust crate that cannot be built here) on a bounded
+    sample of the same workload, on every core this process may use.  Returns (record, oracle proof result)."""
     import oracle
-    cores = min(os.cpu_count() or 1, 16)
+    cores, nproc, quota = host_cores()
     N = 1 << (sample_log_n + log_b)
     oracle.set_threads(cores)
-    oracle.prove(sample_log_n - 3, log_b, want_vectors=False)        # page in, spin up threads
+    oracle.prove(max(sample_log_n - 3, 4), log_b, want_vectors=False)        # page in, spin up threads
     t0 = time.perf_counter()
     r = oracle.prove(sample_log_n, log_b, want_vectors=False)
     dt_all = time.perf_counter() - t0
@@ -71,25 +125,60 @@ def cpu_baseline(sample_log_n, log_b):
     rn = oracle.prove(10, 3, mode=oracle.MODE_NAIVE, want_vectors=False)
     dt_naive = time.perf_counter() - t0
     assert rn.rc == 0
-    return {
+    oracle.set_threads(cores)
+    rec = {
         "reference_algorithm": {"workload": "configs[0]: trace 1023, domain 8192, literal polynomial.rs arithmetic (O(n^3)), 1 thread",
                                 "seconds": dt_naive, "value": 8192 / dt_naive, "unit": "field-elements/s"},
         "value": N / dt_all, "unit": "field-elements/s", "cores": cores, "kind": "port",
-        "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads, {dt_all:.2f} s",
+        "nproc": nproc, "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
+        "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads "
+                  f"(nproc = {nproc}, host logical CPUs = {os.cpu_count()}), {dt_all:.2f} s",
         "single_thread_value": (N // 8) / dt_one,
         "single_thread_sample": f"domain 2^{sample_log_n + log_b - 3}, 1 thread, {dt_one:.2f} s",
     }
+    return rec, r
+
+
+def traffic_record():
+    if not os.path.exists(PROFILE_TRAFFIC):
+        return None, None
+    with open(PROFILE_TRAFFIC) as f:
+        t = json.load(f)
+    return t.get("merkle_leaf_bytes_per_launch"), {k: t.get(k) for k in ("commit", "build_hash", "collected") if k in t}
+
+
+def staged_leg(zk, log_n, log_b, device):
+    """The stage-by-stage API once (zk_lde, zk_merkle_commit, zk_compose, zk_fri_fold): the stand-alone
+    compose_kernel and fri_fold_kernel, which the one-call prover fuses into leaf hashing, timed with HIP events."""
+    with zk.Context(log_n, log_b, device=device) as c:
+        c.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        ch = zk.Channel()
+        for rep in range(2):                                # second pass is the measured one
+            c.set_profiling("all" if rep else ())
+            c.kernel_stats(reset=True)
+            c.lde()
+            c.merkle_commit(0)
+            c.compose([361545003, 3235878091, 2708123352])
+            c.merkle_commit(1)
+            for r in range(4):
+                c.fri_fold(r, 4195595581 + r)
+            c.sync()
+        st = c.kernel_stats(reset=True)
+        c.set_profiling(())
+    return {k: st[k] for k in ("compose", "fri_fold", "ntt")}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                         # nothing here has touched torch or the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.plain_collectives:
+        os.environ["ZK_SHARD_PLAIN"] = "1"
 
     # stdout carries exactly one JSON line: native libraries (RCCL prints a banner when a communicator is
     # created) write to file descriptor 1 directly, so it is pointed at stderr for the duration of the run
@@ -100,19 +189,27 @@ def main():
     import torch
     import torch.distributed as dist
     import zkstark_amd as zk
+    from zkstark_amd import _lib
 
-    # ZK_BENCH_STAGED=1 rehearses the N > 1 path on a one-GPU box: every rank uses cuda:0 and the
-    # collectives go through gloo (host-staged).  Never a measurement configuration.
+    # ZK_BENCH_STAGED=1 rehearses the N > 1 path on a one-GPU box: every rank uses cuda:0 and the collectives
+    # are staged through host memory (gloo).  Never a measurement configuration.
     staged = os.environ.get("ZK_BENCH_STAGED") == "1"
+    force_sharded = os.environ.get("ZK_BENCH_FORCE_SHARDED") == "1"      # the N > 1 code path (RCCL) with one rank
+    sharded_run = world > 1 or force_sharded
     if staged:
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if ndev <= local_rank:
+        print(f"[bench] rank {rank}: --gpus {world} needs {world} GPUs on this node, {ndev} visible", file=sys.stderr, flush=True)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if sharded_run:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if staged:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
+        # control plane only (unique id broadcast, barriers, max over ranks of the time): gloo on the host.  The data
+        # path is RCCL inside the library (zk_shard_*: grouped ncclSend/ncclRecv all-to-all, ncclAllGather).
+        dist.init_process_group("gloo")
 
     def barrier():
         if dist.is_initialized():
@@ -120,21 +217,93 @@ def main():
         torch.cuda.synchronize()
 
     log_n, log_b = args.log_n, args.log_blowup
-    N = 1 << (log_n + log_b)
+    lib = _lib.load()
 
-    # ZK_BENCH_FORCE_SHARDED=1: run the N > 1 code path (sharded prover + RCCL collectives) with one rank
-    force_sharded = os.environ.get("ZK_BENCH_FORCE_SHARDED") == "1"
-    if world > 1 or force_sharded:
-        from zkstark_amd import sharded
-        if world == 1:
-            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
-                os.environ.setdefault(k, v)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        result = sharded.bench(args, rank, local_rank, world, barrier, staged=staged, force=force_sharded)
-        log_n = result["log_n"]
+    def dev_stats():
+        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
+        _lib.check(lib.zk_dev_kernel_stats(arr, len(arr), 1))
+        return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes, "ops": a.ops} for name, a in zip(_lib.KERNEL_CLASSES, arr)}
+
+    result = {}
+    oracle_proof = None
+    if args.staged_only:
+        out = {"staged": staged_leg(zk, log_n, log_b, local_rank)}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
+    if sharded_run:
+        lg = world.bit_length() - 1
+        log_n = args.log_n + lg                              # weak scaling: per-GPU work equals the single-GPU workload
+        uid = [zk.shard_unique_id() if (rank == 0 and not staged) else None]
+        if staged:
+            uid = [os.urandom(128) if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        transport = None
+        if staged:
+            from zkstark_amd import sharded
+            transport = sharded.staged_transport()
+        sp = zk.ShardContext(log_n, log_b, rank, world, uid[0], device=local_rank, transport=transport,
+                             force_collectives=force_sharded, no_root_board=args.plain_collectives)
+        trace = zk.trace_fibsq((1 << log_n) - 1)
+        sp.trace_upload(trace)
+        for _ in range(max(args.warmup, 1)):
+            proof = sp.prove()
+        _lib.check(lib.zk_dev_set_profiling(1 << _lib.KERNEL_CLASSES.index("merkle_leaf")))   # dominant kernel only
+        dev_stats()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            proof = sp.prove()
+        barrier()
+        dt = time.perf_counter() - t0
+        dom = dev_stats()["merkle_leaf"]
+        st = sp.stats()
+        _lib.check(lib.zk_dev_set_profiling((1 << len(_lib.KERNEL_CLASSES)) - 1))
+        sp.prove()
+        per_kernel = dev_stats()
+        _lib.check(lib.zk_dev_set_profiling(0))
         N = 1 << (log_n + log_b)
+        # parity: every rank's bytes must equal the single-GPU prover's (itself pinned on the CPU oracle by the tests)
+        parity = None
+        if rank == 0:
+            proof.verify(strict=True)
+            try:
+                with zk.Context(log_n, log_b, device=local_rank) as c1:
+                    one = c1.prove(trace)
+                parity = {"against": f"single-GPU prover at domain 2^{log_n + log_b} (oracle-pinned)", "equal": one.data == proof.data and one.state == proof.state}
+            except zk.ZkError as e:
+                parity = {"against": "single-GPU prover", "equal": None, "skipped": str(e)}
+        agree = [proof.data[:64] + proof.state]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, agree[0])
+        same_everywhere = all(g == gathered[0] for g in gathered)
+        lde_commit = None
+        if not args.no_secondary:                            # BASELINE.json configs[3] shape
+            root0 = sp.lde_commit()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                root1 = sp.lde_commit()
+            barrier()
+            dtl = (time.perf_counter() - t0) / 10
+            lde_commit = {"workload": f"configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit, domain 2^{log_n + log_b} over {world} GPUs",
+                          "ms": dtl * 1e3, "value": N / dtl, "unit": "field-elements/s", "root_stable": root0 == root1,
+                          "all_to_all_bytes_per_rank": sp.stats()["all_to_all_bytes"]}
+        result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": st["setup_ms"], "device_bytes": int(st["device_bytes"]),
+                  "lde_commit_sharded": lde_commit, "proof_bytes": len(proof.data), "scaling": "weak", "units": N * args.steps,
+                  "parallelism": f"one proof sharded over {world} GPUs (cyclic domain; native RCCL all-to-all per commitment)" if not staged
+                                 else f"REHEARSAL: {world} ranks on one GPU, host-staged collectives",
+                  "shard": {**st, "sent_bytes_per_proof_per_rank": st["sent_bytes"], "ranks_agree": same_everywhere,
+                            "exchanged_bytes_per_element": st["all_to_all_bytes"] * world / N if world > 1 else 0.0},
+                  "parity": parity}
+        sp.close()
+        if parity and parity.get("equal") is False:
+            print("[bench] sharded proof differs from the single-GPU prover", file=sys.stderr, flush=True)
+            sys.exit(4)
+        if not same_everywhere:
+            print("[bench] the ranks disagree on the proof", file=sys.stderr, flush=True)
+            sys.exit(4)
     else:
+        N = 1 << (log_n + log_b)
         ctx = zk.Context(log_n, log_b, device=local_rank, hash=args.hash)
         trace = zk.trace_fibsq((1 << log_n) - 1)
         ctx.trace_upload(trace)                      # resident before the timed region
@@ -158,19 +327,31 @@ def main():
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": ctx.setup_ms,
                   "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
                   "units": N * args.steps, "parallelism": "single-gpu", "host_levels": list(ctx.host_levels)}
-        # secondary figure: BASELINE.json configs[1], domain 2^20 LDE + Merkle commit (trace resident -> root on host)
+        # soak: keep the device busy for a few seconds (driver-side sampling sees it; steady-state figure)
+        if args.soak_seconds > 0:
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < args.soak_seconds:
+                ctx.prove(); k += 1
+            ds = time.perf_counter() - t0
+            result["soak"] = {"seconds": round(ds, 2), "proofs": k, "ms_per_proof": ds / k * 1e3, "value": N * k / ds, "unit": "field-elements/s"}
         if args.hash == "sha256" and not args.no_secondary:
+            # stand-alone compose / fold kernels (fused into leaf hashing in the timed path)
+            result["staged"] = staged_leg(zk, log_n, log_b, local_rank)
+            # secondary figure: BASELINE.json configs[1], domain 2^20 LDE + Merkle commit (trace resident -> root on host)
             with zk.Context(17, 3, device=local_rank) as c2:
                 c2.trace_upload(zk.trace_fibsq((1 << 17) - 1))
-                for _ in range(3):
+                for _ in range(5):
                     c2.lde(); c2.merkle_commit(0)
                 t0 = time.perf_counter()
-                for _ in range(20):
+                for _ in range(50):
                     c2.lde(); c2.merkle_commit(0)
-                dt2 = (time.perf_counter() - t0) / 20
+                dt2 = (time.perf_counter() - t0) / 50
+            floor_us = ((1 << 20) * SHA_LEAF_OPS + ((1 << 20) - 1) * SHA_INNER_OPS) / (VALU_PEAK_TOPS * 1e12) * 1e6
             result["lde_commit_2e20"] = {"workload": "configs[1]: domain 2^20 LDE + Merkle commit", "us": dt2 * 1e6,
-                                         "value": (1 << 20) / dt2, "unit": "field-elements/s"}
-        if args.hash == "sha256" and not args.no_secondary:
+                                         "value": (1 << 20) / dt2, "unit": "field-elements/s",
+                                         "valu_floor_us": floor_us, "frac_of_valu_floor": floor_us / (dt2 * 1e6),
+                                         "hbm_floor_us": 73.5 * (1 << 20) / (HBM_PEAK_GBS * 1e9) * 1e6}
             # configs[0] on the GPU path: the reference's own size (trace 1023, domain 8192)
             with zk.Context(10, 3, device=local_rank) as c0:
                 c0.trace_upload(zk.trace_fibsq(1023))
@@ -201,8 +382,9 @@ def main():
             for c in ctxs[1:]:
                 c.trace_upload(trace)
                 c.prove()
+            reps = min(args.steps, 20)
             def work(c):
-                for _ in range(args.steps):
+                for _ in range(reps):
                     c.prove()
             barrier()
             t0 = time.perf_counter()
@@ -211,16 +393,16 @@ def main():
             [t.join() for t in th]
             barrier()
             dtp = time.perf_counter() - t0
-            result["pipelined"] = {"proofs_in_flight": args.in_flight, "value": args.in_flight * N * args.steps / dtp,
-                                   "unit": "field-elements/s", "ms_per_proof": dtp / (args.in_flight * args.steps) * 1e3}
+            result["pipelined"] = {"proofs_in_flight": args.in_flight, "value": args.in_flight * N * reps / dtp,
+                                   "unit": "field-elements/s", "ms_per_proof": dtp / (args.in_flight * reps) * 1e3}
             for c in ctxs[1:]:
                 c.close()
         ctx.close()
 
     dt = result["dt"]
-    if world > 1 or force_sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if sharded_run:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)         # the slowest rank's time
         dt = float(t.item())
 
     if rank == 0:
@@ -228,41 +410,37 @@ def main():
         value = result["units"] / dt
         dom = result["dom"]
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
-        traffic = None
-        if os.path.exists(PROFILE_TRAFFIC):
-            with open(PROFILE_TRAFFIC) as f:
-                traffic = json.load(f).get("merkle_leaf_bytes_per_launch")
-        hw_valu = None
-        if os.path.exists(PROFILE_VALU):
-            with open(PROFILE_VALU) as f:
-                ks = [k for k in json.load(f)["kernels"] if "merkle_subtree_kernel" in k["kernel"] and ", true," in k["kernel"]]
-            if ks:   # the largest leaf launch: issue-slot utilisation and the clock the chip held (hardware counters)
-                big = max(ks, key=lambda k: k["duration_us"])
-                hw_valu = {"utilization": big["valu_utilization"], "clock_ghz": big["clock_ghz"], "kernel": big["kernel"],
-                           "source": "rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE (profiles/valu_utilization.json)"}
-        # SHA-256 work of the dominant kernel in 32-bit lane-ops (1 leaf + inner hashes)
+        traffic, traffic_stamp = traffic_record()
         roofline = {
             "kernel": "merkle_subtree_kernel<leaf>", "bound": "hbm",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic,
+            "traffic": traffic if (args.hash == "sha256" and not sharded_run) else None, "traffic_stamp": traffic_stamp,
             "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
             "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
             "note": "SHA-256 is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu{}; stages[] lists the HBM-bound kernels",
             "valu": {"achieved": dom["ops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0, "peak": VALU_PEAK_TOPS,
                      "unit": "T lane-ops/s (32-bit)",
                      "frac": (dom["ops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS) if dom["ms"] > 0 else 0.0,
-                     "ops_per_leaf_hash": 1259 if args.hash == "sha256" else 10200,
-                     "ops_per_inner_hash": 2293 if args.hash == "sha256" else 10300,
-                     "hw_counters": hw_valu if args.hash == "sha256" else None},
+                     "ops_per_leaf_hash": SHA_LEAF_OPS if args.hash == "sha256" else 10200,
+                     "ops_per_inner_hash": SHA_INNER_OPS if args.hash == "sha256" else 10300,
+                     "peak_basis": "64 lanes/clk/CU x 256 CUs x 2.4 GHz; measured at 1/2/4/8 waves per SIMD (profiles/r02_valu_microbench.txt)"},
         }
         stages = []
-        for name, st in result["per_kernel"].items():
+        def add_stage(name, st, note=None):
             if st["launches"]:
                 gbs = st["bytes"] / (st["ms"] * 1e-3) / 1e9 if st["ms"] > 0 else 0.0
-                stages.append({"kernel": name, "launches": st["launches"], "ms": round(st["ms"], 4),
-                               "algorithmic_GB": round(st["bytes"] / 1e9, 4), "GBps": round(gbs, 1),
-                               "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                               "valu_frac": round(st["ops"] / (st["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4) if st["ms"] > 0 and st["ops"] else None})
+                row = {"kernel": name, "launches": st["launches"], "ms": round(st["ms"], 4),
+                       "algorithmic_GB": round(st["bytes"] / 1e9, 4), "GBps": round(gbs, 1),
+                       "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "valu_frac": round(st["ops"] / (st["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4) if st["ms"] > 0 and st["ops"] else None}
+                if note:
+                    row["note"] = note
+                stages.append(row)
+        for name, st in result["per_kernel"].items():
+            add_stage(name, st)
+        for name, st in (result.get("staged") or {}).items():
+            if name != "ntt":
+                add_stage(name + " (stand-alone)", st, "stage-by-stage API: this kernel is fused into leaf hashing in the timed path")
         out = {
             "metric": "field-elements/s through LDE+Merkle+FRI (full STARK-101 prover)",
             "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps,
@@ -271,25 +449,39 @@ def main():
             "data": "synthetic Fibonacci-square trace (a0=1, a1=3141592), deterministic",
             "config": {"workload": f"full prover: LDE + compose + FRI + Merkle, domain 2^{log_n + log_b} "
                                    f"(trace group 2^{log_n}, blow-up {1 << log_b})" + (f" per proof; {result['parallelism']}" if world > 1 else ""),
-                       "log_n": log_n, "log_blowup": log_b, "domain": N, "fri_rounds": log_n, "merkle_hash": args.hash,
+                       "log_n": log_n, "log_blowup": log_b, "domain": 1 << (log_n + log_b), "fri_rounds": log_n, "merkle_hash": args.hash,
                        "parallelism": result["parallelism"],
                        # host thread's share of the latency-bound end: [tree-top levels, log2 of the largest host-side FRI layer]
                        "host_levels": result.get("host_levels")},
             "roofline": roofline,
             "stages": stages,
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],
-            "proof_bytes": result["proof_bytes"],
+            "proof_bytes": result["proof_bytes"], "build_hash": _lib.build_hash(),
         }
-        if "pipelined" in result:
-            out["pipelined"] = result["pipelined"]
-        for k in ("lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded"):
+        for k in ("pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "shard"):
             if result.get(k) is not None:
                 out[k] = result[k]
-        if world == 1 and not args.no_cpu_baseline and args.hash == "sha256":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_b)
+        if sharded_run:
+            out["parity_checked"] = bool(result["parity"] and result["parity"].get("equal"))
+            out["parity"] = result["parity"]
+        if world == 1 and not sharded_run and not args.no_cpu_baseline and args.hash == "sha256":
+            sample = args.cpu_sample_log_n if args.cpu_sample_log_n is not None else log_n
+            out["cpu_baseline"], oracle_proof = cpu_baseline(sample, log_b)
+            if sample == log_n:
+                # the timed proof against the oracle's proof of the same trace: every byte, and the final channel state
+                ok = proof.data == oracle_proof.proof and proof.state == oracle_proof.state
+                out["parity_checked"] = bool(ok)
+                out["parity"] = {"against": f"CPU oracle, full proof bytes + channel state at domain 2^{log_n + log_b}", "equal": bool(ok)}
+                if not ok:
+                    print("[bench] PARITY FAILURE: the timed proof differs from the CPU oracle's", file=sys.stderr, flush=True)
+            else:
+                out["parity_checked"] = False
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or force_sharded:
+        if out.get("parity_checked") is False and out.get("parity", {}).get("equal") is False:
+            sys.exit(4)
+    if sharded_run:
+        dist.barrier()
         dist.destroy_process_group()
 
 

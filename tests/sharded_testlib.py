@@ -139,48 +139,6 @@ class ChunkingOracleBackend(OracleBackend):
 
 # ---- a caller-supplied zk_shard_transport for tests: gloo, staged through host memory ----------------------
 def gloo_transport(dist_group=None):
-    """The two collectives of the native sharded prover (include/zkstark_amd.h: zk_shard_transport) over
-    torch.distributed/gloo with device buffers staged through the host: lets several ranks share ONE GPU (RCCL
-    needs a GPU per rank).  Returns a _lib.ShardTransport; keep it alive as long as the shard."""
-    import ctypes as C
-    import os
-    import traceback
-    import torch.distributed as dist
-    from zkstark_amd import _lib
-    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # the runtime already loaded
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-    D2H, H2D = 2, 1
-    world = dist.get_world_size(dist_group)
-
-    def d2h(ptr, words):
-        t = torch.empty(words, dtype=torch.int32)
-        assert hip.hipMemcpy(t.data_ptr(), ptr, words * 4, D2H) == 0
-        return t
-
-    def all_to_all(user, send, recv, words, stream):
-        try:
-            assert hip.hipStreamSynchronize(stream) == 0
-            s = torch.cat([d2h(send[p], words) for p in range(world)])
-            r = torch.empty_like(s)
-            dist.all_to_all_single(r, s, group=dist_group)
-            for q in range(world):
-                assert hip.hipMemcpy(recv[q], r[q * words:(q + 1) * words].data_ptr(), words * 4, H2D) == 0
-            return 0
-        except Exception:                                  # a ctypes callback must not raise
-            traceback.print_exc()
-            return 1
-
-    def all_gather(user, send, recv, words, stream):
-        try:
-            assert hip.hipStreamSynchronize(stream) == 0
-            s = d2h(send, words)
-            r = torch.empty(words * world, dtype=torch.int32)
-            dist.all_gather_into_tensor(r, s, group=dist_group)
-            assert hip.hipMemcpy(recv, r.data_ptr(), words * 4 * world, H2D) == 0
-            return 0
-        except Exception:
-            traceback.print_exc()
-            return 1
-
-    return _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(all_to_all), _lib.ALL_GATHER_FN(all_gather))
+    """zkstark_amd.sharded.staged_transport: lets several ranks share ONE GPU (RCCL needs a GPU per rank)."""
+    from zkstark_amd import sharded
+    return sharded.staged_transport(dist_group)

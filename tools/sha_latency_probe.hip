@@ -1,0 +1,84 @@
+// sha_latency_probe.hip -- how long ONE dependent SHA-256 inner hash takes on a wave, which is what bounds the
+// latency phase of a Merkle build (levels with fewer nodes than the chip has lanes: DESIGN.md section 4.3).
+// Every lane runs a chain of CH inner hashes d <- H(d, d ^ c) (merkle.rs:42-45 shape: two compressions, the second
+// on constant padding); waves record their s_memtime lifetime.  Residency 1 and 2 waves per SIMD; variant B hashes
+// two independent chains per lane (does instruction-level parallelism inside one wave buy anything?).
+// Build: hipcc -O3 --offload-arch=gfx950 -I zkstark_amd/csrc -o tools/sha_latency_probe tools/sha_latency_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "sha256.hpp"
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+using namespace zk;
+constexpr int CH = 16;
+
+template <int CHAINS>
+__global__ __launch_bounds__(256) void probe(uint32_t* out, uint32_t seed, unsigned long long* rec) {
+    Digest d[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[c].w[i] = seed * (i + 1 + 8 * c) + threadIdx.x + blockIdx.x * 977;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < CH; ++it) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) {
+            Digest r = d[c];
+            r.w[0] ^= seed;
+            d[c] = sha256_inner(d[c], r);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t x = 0;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x ^= d[c].w[i];
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+    if ((threadIdx.x & 63) == 0) {
+        rec[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = c1 - c0;
+        rec[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int CHAINS>
+int run(int cus, int wps, uint32_t* d_out, unsigned long long* d_rec) {
+    const int blocks = cus * wps;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(probe<CHAINS>, dim3(blocks), dim3(256), 0, 0, d_out, 3u, d_rec);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL(probe<CHAINS>, dim3(blocks), dim3(256), 0, 0, d_out, 5u, d_rec);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h((size_t)blocks * 8);
+    CHK(hipMemcpy(h.data(), d_rec, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> cyc, ghz;
+    for (size_t i = 0; i < h.size(); i += 2) { cyc.push_back((double)h[i] / (CH * CHAINS)); ghz.push_back((double)h[i] / (double)h[i + 1] * 0.1); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
+    const double c = cyc[cyc.size() / 2], g = ghz[ghz.size() / 2];
+    printf("%d chain(s) per lane, %d wave(s) per SIMD: %8.0f cycles per inner hash per wave (%.2f us at %.2f GHz; %.2f cycles per instruction of 2293); kernel %.1f us for %d hashes deep\n",
+           CHAINS, wps, c, c / g / 1e3, g, c / 2293.0, ms * 1e3, CH * CHAINS);
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    uint32_t* d_out; unsigned long long* d_rec;
+    CHK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4));
+    CHK(hipMalloc(&d_rec, (size_t)cus * 8 * 4 * 16));
+    for (int wps : {1, 2, 4}) if (run<1>(cus, wps, d_out, d_rec)) return 1;
+    for (int wps : {1, 2}) if (run<2>(cus, wps, d_out, d_rec)) return 1;
+    return 0;
+}

@@ -23,7 +23,8 @@
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-constexpr int ITER = 4096;
+constexpr int ITER = 128;    // outer iterations (a loop branch each: amortised over UNROLL * ACC = 256 VALU instructions)
+constexpr int UNROLL = 32;
 constexpr int ACC = 8;
 
 struct WaveRec { unsigned long long cycles, real; uint32_t hw_id, xcc_id; };
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(256) void bench(uint32_t* out, uint32_t seed, WaveR
 #pragma unroll 1
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
         for (int i = 0; i < ACC; ++i) {
             if (OP == 0) a[i] = __builtin_amdgcn_alignbit(a[i], a[i], 7);             // v_alignbit_b32
             if (OP == 1) a[i] = a[i] + a[(i + 1) & (ACC - 1)] + k;                     // v_add3_u32
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void bench(uint32_t* out, uint32_t seed, WaveR
             if (OP == 8) a[i] = (a[i] << 30) + a[i];                                    // v_lshl_add_u32
             if (OP == 9) pf[i] = __builtin_elementwise_fma(pf[i], pk, pm);              // v_pk_fma_f32: 2 fp32 FMAs per lane
         }
+      }
     }
     uint32_t r = 0;
 #pragma unroll
@@ -89,7 +93,7 @@ int run(const char* name, int lanes_per_op, uint32_t* d_out, WaveRec* d_rec, int
         std::vector<double> cpi, ghz;
         std::map<uint64_t, int> per_simd;
         for (const WaveRec& w : h) {
-            cpi.push_back((double)w.cycles / ((double)ITER * ACC));
+            cpi.push_back((double)w.cycles / ((double)ITER * UNROLL * ACC));
             ghz.push_back((double)w.cycles / (double)w.real * 0.1);            // s_memrealtime ticks at 100 MHz
             // HW_ID (gfx9 layout): simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]
             const uint64_t key = ((uint64_t)(w.xcc_id & 0xF) << 16) | (w.hw_id & 0xFF30u);
@@ -100,7 +104,7 @@ int run(const char* name, int lanes_per_op, uint32_t* d_out, WaveRec* d_rec, int
         int max_res = 0;
         for (auto& kv : per_simd) max_res = std::max(max_res, kv.second);
         const double clock = ghz[ghz.size() / 2];
-        const double ops = (double)reps * blocks * 256.0 * ITER * ACC * lanes_per_op;
+        const double ops = (double)reps * blocks * 256.0 * ITER * UNROLL * ACC * lanes_per_op;
         const double tops = ops / (ms * 1e-3) / 1e12;
         printf("%-15s %d waves/SIMD launched | %7.3f ms %6.2f T lane-ops/s  clock %.2f GHz  %6.1f lanes/clk/CU | wave cycles/instr %5.2f | SIMDs used %4zu, most waves on one SIMD %d\n",
                name, wps, ms / reps, tops, clock, tops * 1e12 / cus / (clock * 1e9), cpi[cpi.size() / 2], per_simd.size(), max_res);

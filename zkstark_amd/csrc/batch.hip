@@ -63,6 +63,10 @@ struct zk_batch {
     ScatterSeg* d_segs = nullptr;
     uint32_t n_segs = 0;
     double seg_words = 0;
+    // A batch of ONE proof is a single proof: it runs on the one-call prover (zk_prove_resident: fused host tail,
+    // no per-round challenge table), so the smallest batch is never slower than zk_prove.
+    zk_ctx* single = nullptr;
+    std::vector<uint32_t> single_trace;
 };
 
 namespace {
@@ -75,6 +79,7 @@ uint32_t blayer_log(const zk_batch* b, uint32_t layer) { return layer == 0 ? b->
 uint32_t bextra(const zk_batch* b, uint32_t log_m) {
     if (!b->host_levels || b->hash != 0 || b->lb >= kMaxHostLog || log_m < 2) return 0;
     uint32_t h = kMaxHostLog - b->lb;
+    if (h > 8) h = 8;                                    // <= 255 nodes per proof on one thread (~8 us), as the single prover
     if (h > log_m - 1) h = log_m - 1;
     return h >= 3 ? h : 0;                               // two levels are not worth a hand-over
 }
@@ -142,6 +147,7 @@ extern "C" {
 int zk_batch_destroy(zk_batch* b) {
     if (!b) return ZK_OK;
     (void)hipSetDevice(b->device);
+    if (b->single) zk_ctx_destroy(b->single);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     dom_free(b->dom);
     for (void* p : {(void*)b->d_trace, (void*)b->d_coef, (void*)b->d_layers, (void*)b->d_trees, (void*)b->d_seed, (void*)b->d_chal,
@@ -168,6 +174,14 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
     b->n = (size_t)1 << log_n; b->B = (size_t)1 << log_b; b->N = b->n << log_b; b->batch = (size_t)1 << log_batch;
     int rc = ZK_OK;
     auto bail = [&](int code) { zk_batch_destroy(b); return code; };
+    if (log_batch == 0) {                                  // one proof: the single prover
+        if ((rc = zk_ctx_create(device, log_n, log_b, &b->single))) return bail(rc);
+        b->first.assign(1, 0);
+        b->last.assign(1, 0);
+        b->device_bytes = zk_ctx_device_bytes(b->single);
+        *out = b;
+        return ZK_OK;
+    }
 #define HIPCHK_B(expr)                                                                        \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
@@ -233,6 +247,7 @@ size_t zk_batch_size(const zk_batch* b) { return b ? b->batch : 0; }
 int zk_batch_set_queries(zk_batch* b, uint32_t n_queries) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
     if (n_queries < 1 || n_queries > 16) return fail(ZK_ERR_INVALID, "zk_batch_set_queries: need 1 <= n_queries <= 16");
+    if (b->single) { b->queries = n_queries; return zk_ctx_set_queries(b->single, n_queries); }
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
     return n_queries == b->queries ? (int)ZK_OK : balloc_gather(b, n_queries);
@@ -241,6 +256,7 @@ int zk_batch_set_hash(zk_batch* b, int hash_kind) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
     if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_batch_set_hash: unknown hash %d", hash_kind);
     b->hash = hash_kind;
+    if (b->single) return zk_ctx_set_hash(b->single, hash_kind);
     return ZK_OK;
 }
 size_t zk_batch_device_bytes(const zk_batch* b) { return b ? b->device_bytes : 0; }
@@ -248,6 +264,13 @@ size_t zk_batch_device_bytes(const zk_batch* b) { return b ? b->device_bytes : 0
 // traces: [batch][n-1] canonical residues on the host (prover.rs:32-39 per proof)
 int zk_batch_set_traces(zk_batch* b, const uint32_t* traces) {
     if (!b || !traces) return fail(ZK_ERR_INVALID, "zk_batch_set_traces: null argument");
+    if (b->single) {
+        int rc = zk_trace_upload(b->single, traces, b->n - 1);
+        if (rc) return rc;
+        b->first[0] = traces[0]; b->last[0] = traces[b->n - 2];
+        b->have_traces = true;
+        return ZK_OK;
+    }
     HIPCHK(hipSetDevice(b->device));
     for (size_t p = 0; p < b->batch * (b->n - 1); ++p)
         if (traces[p] >= P) return fail(ZK_ERR_INVALID, "zk_batch_set_traces: value %zu is not a canonical residue", p);
@@ -261,6 +284,12 @@ int zk_batch_set_traces(zk_batch* b, const uint32_t* traces) {
 // Fibonacci-square traces generated on the device from per-proof seeds (one lane per trace).
 int zk_batch_gen_fibsq(zk_batch* b, const uint32_t* a0, const uint32_t* a1) {
     if (!b || !a0 || !a1) return fail(ZK_ERR_INVALID, "zk_batch_gen_fibsq: null argument");
+    if (b->single) {                                       // prover.rs:32-39 is serial: one trace gains nothing from the device
+        b->single_trace.resize(b->n - 1);
+        int rc = zk_trace_fibsq(a0[0], a1[0], b->n - 1, b->single_trace.data());
+        if (!rc) rc = zk_batch_set_traces(b, b->single_trace.data());
+        return rc;
+    }
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipMemcpyAsync(b->d_seed, a0, b->batch * 4, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_seed + b->batch, a1, b->batch * 4, hipMemcpyHostToDevice, b->stream));
@@ -289,6 +318,12 @@ int zk_batch_prove(zk_batch* b, uint8_t* proofs_out, size_t stride, uint8_t* sta
     const int hash = b->hash;
     const size_t plen = proof_data_len(b->log_n, b->log_b, Q);
     if (stride < plen) return fail(ZK_ERR_BUFFER, "zk_batch_prove: stride %zu < proof length %zu", stride, plen);
+    if (b->single) {
+        size_t len = 0;
+        int rc1 = zk_prove_resident(b->single, proofs_out, stride, &len, states_out);
+        if (rc1 == ZK_ERR_CHECK) return fail(ZK_ERR_CHECK, "proof 0 of the batch: %s", last_error());
+        return rc1;
+    }
     HIPCHK(hipSetDevice(b->device));
     const size_t nb = b->batch, N = b->N, B = b->B;
     const uint32_t R = b->R, L = b->L, lb = b->lb;

@@ -36,7 +36,7 @@ Plan make_plan(uint32_t log_m) {
 }
 
 uint32_t pick_logC(uint32_t log_total, uint32_t logR) {
-    uint32_t cols = log_total - logR, cap = kTileLog - logR;
+    uint32_t cols = log_total - logR, cap = ntt_tile_log(log_total) - logR;
     return cols < cap ? cols : cap;
 }
 
@@ -71,7 +71,7 @@ int run_dif(const uint32_t* src, uint32_t* data, uint32_t log_m, const Plan& pl,
         NttPassArgs a{};
         a.batch = batch; a.src_stride = d == 0 ? src_stride : data_stride; a.dst_stride = data_stride;
         a.src = d == 0 ? src : data; a.dst = data; a.log_total = log_m;
-        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR);
+        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR); a.tile_log = ntt_tile_log(log_m);
         a.L = L; a.tw = tw_inv; a.scale_mont = (inner == 0) ? scale_mont : 0;
         HIPCHK(launch_ntt_pass(a, NTT_DIF, s, prof));
     }
@@ -83,7 +83,7 @@ int run_dit(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw, uint32_
     for (int d = (int)pl.nd - 1; d >= 0; --d) {
         NttPassArgs a{};
         a.src = data; a.dst = data; a.log_total = log_m;
-        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR);
+        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR); a.tile_log = ntt_tile_log(log_m);
         a.L = L; a.tw = tw;
         HIPCHK(launch_ntt_pass(a, NTT_DIT, s));
         inner += pl.bits[d];
@@ -148,28 +148,35 @@ int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t
     // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
     int rc = run_dif(d_trace, d_coef, d->log_n, d->plan, d->Hinv.view(), d->L, 0, s, prof, batch, ts, cs);
     if (rc) return rc;
-    // virtual-point correction, coset shift and 1/n: d_coef[0..n) -> d_coef[n..2n)
+    // virtual-point correction, coset shift and 1/n (coef_prepare): as its own sweep d_coef[0..n) -> d_coef[n..2n), or,
+    // for small n (latency-bound: every launch counts), applied by the first LDE pass as it loads the coefficients
     uint32_t* d_prep = d_coef + d->n;
-    {
-        CoefPrepArgs pa{};
-        pa.log_n = d->log_n; pa.log_b = d->log_b;
-        pa.tw = d->H.view(); pa.wtab = d->W.view(); pa.ninv_mont = d->ninv_mont;
-        pa.nd = d->plan.nd;
-        for (uint32_t t = 0; t < d->plan.nd; ++t) pa.dig_bits[t] = d->plan.bits[t];
-        HIPCHK(launch_coef_prepare(d_coef, d_prep, pa, s, prof, batch, cs, cs));
-    }
+    CoefPrepArgs pa{};
+    pa.log_n = d->log_n; pa.log_b = d->log_b;
+    pa.tw = d->H.view(); pa.wtab = d->W.view(); pa.ninv_mont = d->ninv_mont;
+    pa.nd = d->plan.nd;
+    for (uint32_t t = 0; t < d->plan.nd; ++t) pa.dig_bits[t] = d->plan.bits[t];
     // size-N forward transform of the zero-padded coefficients
     uint32_t inner = d->log_b;
     for (int q = (int)d->plan.nd - 1; q >= 0; --q) {
         NttPassArgs a{};
-        a.log_total = d->L; a.logR = d->plan.bits[q]; a.logS = inner; a.logC = pick_logC(d->L, a.logR);
+        a.log_total = d->L; a.logR = d->plan.bits[q]; a.logS = inner; a.logC = pick_logC(d->L, a.logR); a.tile_log = ntt_tile_log(d->L);
         a.L = d->L; a.tw = d->H.view();
         a.dst = d_out;
         a.batch = batch; a.dst_stride = os; a.src_stride = os;
         if (q == (int)d->plan.nd - 1) {
             if (a.logC < d->log_b) a.logC = d->log_b;
-            a.src = d_prep;
             a.src_stride = cs;
+            const bool fuse = d->log_n <= kFusePrepMaxLogN && ntt_fast_ok(a, NTT_DIT_LDE);
+            if (fuse) {
+                a.src = d_coef;                                   // raw DIF output: prepared at the load
+                a.prep = 1; a.prep_log_n = d->log_n; a.prep_log_b = d->log_b; a.prep_ninv_mont = d->ninv_mont;
+                a.prep_nd = d->plan.nd; a.prep_wtab = d->W.view();
+                for (uint32_t t = 0; t < d->plan.nd; ++t) a.prep_bits[t] = d->plan.bits[t];
+            } else {
+                HIPCHK(launch_coef_prepare(d_coef, d_prep, pa, s, prof, batch, cs, cs));
+                a.src = d_prep;
+            }
             HIPCHK(launch_ntt_pass(a, NTT_DIT_LDE, s, prof));
         } else {
             a.src = d_out;

@@ -34,8 +34,10 @@ constexpr uint32_t kMaxQueries = 64;
 constexpr uint32_t kMaxHostLog = 10;                         // host_top, host_tail, log_batch <= 10
 constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // after the digests of depth host_top
 constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail
-constexpr uint32_t kTileLog = 13;      // 8192 words = 32 KiB per workgroup tile
 constexpr uint32_t kMaxRadixLog = 8;
+// up to this trace size the coefficient preparation is fused into the first LDE pass (each coefficient is then
+// prepared by the B columns that load it: B-fold redundant arithmetic, one launch and one sweep less)
+constexpr uint32_t kFusePrepMaxLogN = 18;
 
 // Sizes a proof can have: shared by zk_ctx_create and zk_batch_create so that everything the provers accept is something
 // the verifier (transcript.hpp: log_n >= 2) can check.  n = 8 is degenerate: g^4 = -1 cancels the leading terms of

@@ -74,19 +74,32 @@ enum NttMode : uint32_t {
     NTT_DIT_LDE = 2,    // first forward pass of the LDE: reads n prepared coefficients, writes N = n*B values
 };
 
+// Workgroup tile of an NTT pass, in words: 8192 for big transforms (HBM-bound: long row segments), 2048 once a pass
+// has fewer than ~1000 big tiles (latency-bound: more workgroups, fewer elements per thread).
+constexpr uint32_t kBigTileLog = 13, kSmallTileLog = 11;
+inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total >= kBigTileLog + 10 ? kBigTileLog : kSmallTileLog; }
+
 struct NttPassArgs {
     const uint32_t* src;
     uint32_t* dst;
     uint32_t log_total;   // log2 of the number of elements of dst
     uint32_t logR, logS;  // this pass: radix and inner stride
     uint32_t logC;        // columns per workgroup tile (tile = R * C elements)
+    uint32_t tile_log;    // log2 of the tile (ntt_tile_log of the pass; the register-radix kernel needs logC = tile_log - logR)
     uint32_t L;           // the table root has order 2^L
     PowTable tw;          // h (forward) or h^-1 (inverse)
     uint32_t scale_mont;  // NTT_DIF only: multiply outputs by this Montgomery constant when S == 1 (n^-1); 0 = none
     // batch of independent transforms (zk_batch_*): grid.y = batch, transform b at src + b*src_stride / dst + b*dst_stride
     uint32_t batch;       // 0 or 1 = a single transform
     size_t src_stride, dst_stride;
+    // NTT_DIT_LDE with prep != 0: src is the raw DIF output U and the coefficient preparation of
+    // coef_prepare_kernel (CoefPrepArgs below) happens at the load; register-radix kernel only (ntt_fast_ok)
+    uint32_t prep;
+    uint32_t prep_log_n, prep_log_b, prep_ninv_mont, prep_nd;
+    uint32_t prep_bits[kMaxDigits];
+    PowTable prep_wtab;   // powers of the coset shift
 };
+bool ntt_fast_ok(const NttPassArgs& a, NttMode mode);
 
 struct CoefPrepArgs {
     uint32_t log_n, log_b;

@@ -1,8 +1,10 @@
-// ntt_fast.hip -- register-radix NTT pass for the full-size tiles (R = 64, 128, 256).
+// ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256).
 //
 // Same pass semantics as ntt_pass_kernel (kernels.hip): the array is [A][R][S], a workgroup owns
-// C columns x R rows (R*C = 8192 words).  Here the R-point transform is a four-step inside the
-// tile, R = Ra*Rb with Ra, Rb <= 16:
+// C columns x R rows.  The tile is R*C = 8192 words for large transforms and 2048 words for small
+// ones (NttPassArgs.tile_log: a 2^17-point transform is then 64 workgroups instead of 16, and every
+// thread handles 8 elements instead of 32 -- those passes are latency-bound, not bandwidth-bound).
+// The R-point transform is a four-step inside the tile, R = Ra*Rb with Ra, Rb <= 16:
 //
 //   step 1  thread (tb, c): loads rows ta*Rb + tb, ta < Ra, straight into registers (lanes run
 //           along c: one 256 B row segment per wave-instruction), applies the inter-pass twiddle
@@ -76,16 +78,19 @@ __device__ __forceinline__ uint32_t pow_lookup(const PowTable& t, uint32_t e) {
 }
 
 constexpr int kThreads = 256;
-constexpr uint32_t kTileLog = 13;
 
 // MODE: NTT_DIF (inverse passes: DFT with w^-1, post-twiddle), NTT_DIT (forward passes: pre-twiddle),
 //       NTT_DIT_LDE (forward, S = B, source = n prepared coefficients, each feeding B columns).
 // STAGED: the tile is one contiguous block of HBM (S < C): go through LDS for full-line accesses.
-template <uint32_t MODE, int LA, int LB, bool STAGED>
+// PREP (NTT_DIT_LDE only): the source is the raw DIF output U of the inverse transform and the
+//   interpolant's coefficient preparation (coef_prepare_kernel: virtual last trace point, coset shift,
+//   1/n) is applied to every value as it is loaded -- one launch and one pass over the coefficients less.
+template <uint32_t MODE, int LA, int LB, bool STAGED, int TILE_LOG, bool PREP>
 __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) {
     constexpr bool INV = (MODE == NTT_DIF);
     constexpr int LOGR = LA + LB, R = 1 << LOGR, RA = 1 << LA, RB = 1 << LB;
-    constexpr int LOGC = (int)kTileLog - LOGR, C = 1 << LOGC;
+    constexpr int LOGC = TILE_LOG - LOGR, C = 1 << LOGC;
+    constexpr uint32_t kTileLog = TILE_LOG;
     constexpr int PITCH = STAGED || MODE == NTT_DIT_LDE ? C + 1 : C;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     p.src += (size_t)blockIdx.y * p.src_stride;      // batch of independent transforms
@@ -127,6 +132,29 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
             const uint32_t a = (col0 + c) >> logS;                 // coefficient block; B columns share it
 #pragma unroll
             for (int ta = 0; ta < RA; ++ta) x[ta] = p.src[((size_t)a << LOGR) | (uint32_t)(ta * RB + tb)];
+            if (PREP) {
+                // storage position (a, t) holds the coefficient of true index k = rev(a) | t << (log_n - LOGR):
+                // the slow storage digits of the digit-reversed DIF output are the LOW digits of k
+                const uint32_t log_n = p.prep_log_n, tsh = log_n - LOGR;
+                uint32_t ka = 0, rem = tsh, sh = 0;
+                for (uint32_t d = 0; d + 1 < p.prep_nd; ++d) {
+                    rem -= p.prep_bits[d];
+                    ka |= ((a >> rem) & ((1u << p.prep_bits[d]) - 1u)) << sh;
+                    sh += p.prep_bits[d];
+                }
+                const uint32_t n1 = (1u << log_n) - 1u;
+                const uint32_t k0 = ka | (tb << tsh), kstep = (uint32_t)RB << tsh;
+                const uint32_t c_top = p.src[n1];                  // U[n-1]
+                // x <- (x - U[n-1] g^(k+1)) * shift^k / n, running products over ta (k advances by kstep)
+                uint32_t gcur = pow_lookup(p.tw, ((k0 + 1u) & n1) << p.prep_log_b);
+                uint32_t wcur = mont_mul(pow_lookup(p.prep_wtab, k0), p.prep_ninv_mont);
+                const uint32_t gstep = pow_lookup(p.tw, (kstep & n1) << p.prep_log_b), wstep = pow_lookup(p.prep_wtab, kstep & n1);
+#pragma unroll
+                for (int ta = 0; ta < RA; ++ta) {
+                    x[ta] = mont_mul(sub(x[ta], mont_mul(c_top, gcur)), wcur);
+                    if (ta + 1 < RA) { gcur = mont_mul(gcur, gstep); wcur = mont_mul(wcur, wstep); }
+                }
+            }
         } else if (STAGED) {
 #pragma unroll
             for (int ta = 0; ta < RA; ++ta) x[ta] = tile[(ta * RB + tb) * PITCH + c];
@@ -158,10 +186,12 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     __syncthreads();
 
     // ---- step 2: Rb-point DFTs over tb (consecutive rows) ----------------------------------
-    uint32_t keep[(RA * C) / kThreads][RB];   // staged stores wait until every thread has read the tile
+    constexpr int IT2 = (RA * C + kThreads - 1) / kThreads;   // RA*C < kThreads (small tile, R = 256): half the threads idle here
+    uint32_t keep[IT2][RB];   // staged stores wait until every thread has read the tile
 #pragma unroll
-    for (int it = 0; it < (RA * C) / kThreads; ++it) {
+    for (int it = 0; it < IT2; ++it) {
         const uint32_t q = tid + it * kThreads;
+        if (RA * C < kThreads && q >= (uint32_t)(RA * C)) continue;
         const uint32_t c = q & (C - 1), ka = q >> LOGC;
         const uint32_t s = (col0 + c) & smask;
         uint32_t (&y)[RB] = keep[it];
@@ -192,8 +222,9 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     if (STAGED) {
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < (RA * C) / kThreads; ++it) {
+        for (int it = 0; it < IT2; ++it) {
             const uint32_t q = tid + it * kThreads;
+            if (RA * C < kThreads && q >= (uint32_t)(RA * C)) continue;
             const uint32_t c = q & (C - 1), ka = q >> LOGC;
 #pragma unroll
             for (int i = 0; i < RB; ++i) tile[(ka + RA * c_brev(i, LB)) * PITCH + c] = keep[it][i];
@@ -208,19 +239,27 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     }
 }
 
-template <uint32_t MODE, int LA, int LB>
-hipError_t launch2(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
-    constexpr int R = 1 << (LA + LB), C = 1 << ((int)kTileLog - LA - LB);
+template <uint32_t MODE, int LA, int LB, int TILE_LOG>
+hipError_t launch3(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
+    constexpr int R = 1 << (LA + LB), C = 1 << (TILE_LOG - LA - LB);
     size_t shmem = ((size_t)R * (C + 1) + R) * sizeof(uint32_t);
     const dim3 grid(blocks, a.batch ? a.batch : 1);
-    if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true>), grid, dim3(kThreads), shmem, s, a);
-    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false>), grid, dim3(kThreads), shmem, s, a);
+    if (MODE == NTT_DIT_LDE && a.prep) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, MODE == NTT_DIT_LDE>), grid, dim3(kThreads), shmem, s, a);
+    else if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, false>), grid, dim3(kThreads), shmem, s, a);
+    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false, TILE_LOG, false>), grid, dim3(kThreads), shmem, s, a);
     return hipGetLastError();
+}
+
+template <uint32_t MODE, int LA, int LB>
+hipError_t launch2(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
+    return a.tile_log == kSmallTileLog ? launch3<MODE, LA, LB, (int)kSmallTileLog>(a, staged, blocks, s)
+                                       : launch3<MODE, LA, LB, (int)kBigTileLog>(a, staged, blocks, s);
 }
 
 template <uint32_t MODE>
 hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
     switch (a.logR) {
+        case 5: return launch2<MODE, 3, 2>(a, staged, blocks, s);
         case 6: return launch2<MODE, 3, 3>(a, staged, blocks, s);
         case 7: return launch2<MODE, 4, 3>(a, staged, blocks, s);
         case 8: return launch2<MODE, 4, 4>(a, staged, blocks, s);
@@ -230,14 +269,22 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
 
 }  // namespace
 
-// Returns true if this pass was launched on the fast path (full 8192-word tiles only).
+// True when launch_ntt_pass_fast will take this pass (the planner asks before it fuses the coefficient
+// preparation into the first LDE pass, which only this kernel implements).
+bool ntt_fast_ok(const NttPassArgs& a, NttMode mode) {
+    if (a.logR < 5 || a.logR > 8) return false;
+    if (a.tile_log != kSmallTileLog && a.tile_log != kBigTileLog) return false;
+    const uint32_t logC = a.tile_log - a.logR;
+    if (a.log_total < a.tile_log || a.logC != logC) return false;
+    if (mode == NTT_DIT_LDE && !(a.logS < logC)) return false;
+    return true;
+}
+
+// Returns true if this pass was launched on the fast path (full tiles only).
 bool launch_ntt_pass_fast(const NttPassArgs& a, NttMode mode, hipStream_t s, hipError_t* err) {
-    if (a.logR < 6 || a.logR > 8) return false;
-    const uint32_t logC = kTileLog - a.logR;
-    if (a.log_total < kTileLog || a.logC != logC) return false;
-    const bool staged = a.logS < logC;
-    if (mode == NTT_DIT_LDE && !staged) return false;
-    const uint32_t blocks = 1u << (a.log_total - kTileLog);
+    if (!ntt_fast_ok(a, mode)) return false;
+    const bool staged = a.logS < a.tile_log - a.logR;
+    const uint32_t blocks = 1u << (a.log_total - a.tile_log);
     switch (mode) {
         case NTT_DIF: *err = launch1<NTT_DIF>(a, staged, blocks, s); break;
         case NTT_DIT: *err = launch1<NTT_DIT>(a, staged, blocks, s); break;

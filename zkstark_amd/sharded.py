@@ -29,6 +29,7 @@ test double that tests inject (tests/test_sharded_gloo.py); there is no CPU fall
 """
 import ctypes as C
 import hashlib
+import os
 import struct
 import time
 
@@ -700,6 +701,60 @@ class ShardedProver:
         self.be.close()
 
 
+def staged_transport(group=None):
+    """A zk_shard_transport (include/zkstark_amd.h) over torch.distributed with the device buffers staged through
+    host memory: for process groups without device collectives (gloo), e.g. several ranks sharing ONE GPU, where
+    RCCL cannot be used.  Never a measurement configuration.  Returns a _lib.ShardTransport; keep it alive as
+    long as the zk_shard that uses it."""
+    import os
+    import traceback
+    import torch
+    import torch.distributed as dist
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # the runtime already loaded
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    D2H, H2D = 2, 1
+    world = dist.get_world_size(group)
+
+    def d2h(ptr, words):
+        t = torch.empty(words, dtype=torch.int32)
+        if hip.hipMemcpy(t.data_ptr(), ptr, words * 4, D2H) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return t
+
+    def h2d(ptr, t):
+        if hip.hipMemcpy(ptr, t.data_ptr(), t.numel() * 4, H2D) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def all_to_all(user, send, recv, words, stream):
+        try:
+            if hip.hipStreamSynchronize(stream) != 0:
+                raise RuntimeError("hipStreamSynchronize failed")
+            s = torch.cat([d2h(send[p], words) for p in range(world)])
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=group)
+            for q in range(world):
+                h2d(recv[q], r[q * words:(q + 1) * words].contiguous())
+            return 0
+        except Exception:                                  # a ctypes callback must not raise
+            traceback.print_exc()
+            return 1
+
+    def all_gather(user, send, recv, words, stream):
+        try:
+            if hip.hipStreamSynchronize(stream) != 0:
+                raise RuntimeError("hipStreamSynchronize failed")
+            r = torch.empty(words * world, dtype=torch.int32)
+            dist.all_gather_into_tensor(r, d2h(send, words), group=group)
+            h2d(recv, r)
+            return 0
+        except Exception:
+            traceback.print_exc()
+            return 1
+
+    return _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(all_to_all), _lib.ALL_GATHER_FN(all_gather))
+
+
 def bench(args, rank, local_rank, world, barrier, staged=False, force=False):
     """bench.py leg for N > 1: one proof over `world` GPUs at domain 2^(log_n + log_blowup) * world
     (weak scaling: per-GPU work equals the single-GPU workload)."""
@@ -714,21 +769,10 @@ def bench(args, rank, local_rank, world, barrier, staged=False, force=False):
     trace = trace_fibsq((1 << log_n) - 1)
     sp.trace_upload(trace)
     lib = _lib.load()
-    conservative = False
-    try:
-        sp.prove()
-    except Exception as e:                            # noqa: BLE001  (same code on every rank: all of them land here together)
-        # the optional accelerations (chunked list exchange, shared-memory root board) are the only parts that
-        # cannot be rehearsed with RCCL on a one-GPU box: fall back to the plain collectives rather than fail
-        if rank == 0:
-            import sys
-            print(f"[bench] sharded prover failed with the optional accelerations ({e}); retrying without them", file=sys.stderr, flush=True)
-        sp.close()
-        be = HipBackend(local_rank)
-        sp = ShardedProver(log_n, args.log_blowup, comm, be, overlap_min_log=99, use_board=False)
-        sp.trace_upload(trace)
-        sp.prove()
-        conservative = True
+    # No silent retry: a failure of the chunked list exchange or of the root board is a defect to look at, not a
+    # reason to measure something else.  --plain-collectives (ZK_SHARD_PLAIN=1) selects the plain path explicitly.
+    conservative = os.environ.get("ZK_SHARD_PLAIN") == "1"
+    sp.prove()
 
     def stats():
         arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
