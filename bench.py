@@ -177,6 +177,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
+    # before anything initialises HIP / HSA: dmabuf IPC for RCCL's peer-to-peer buffers, loopback for the gloo control plane
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 and os.path.isdir("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the container's hostname may not resolve
     if args.plain_collectives:
         os.environ["ZK_SHARD_PLAIN"] = "1"
 

@@ -88,15 +88,17 @@ int zk_ctx_sync(zk_ctx *ctx);
 int zk_ctx_set_queries(zk_ctx *ctx, uint32_t n_queries);
 /* Selects the Merkle hash of every later zk_merkle_commit / zk_prove* on this context. */
 int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
-/* Division of the latency-bound end of zk_prove* between device and host thread.  A Merkle level is a
- * chain of dependent hashes (merkle.rs:40-46): ~4.4 us on a GPU wave, ~31 ns per node on a CPU core with
- * SHA extensions.  With top_log = H > 0 the device builds every SHA-256 tree with more than 2^H leaves
- * down to its 2^H nodes of depth H and the calling thread hashes the 2^H - 1 nodes above; with
- * tail_log = T >= H, FRI layers of <= 2^T values (polynomial.rs:385 fold + merkle.rs:14 tree) are
- * computed by the calling thread as well.  Everything the host built is copied into the device arrays
- * before the call returns, so zk_layer_read / zk_merkle_path see complete trees.  Default: (8, 9) when
- * the CPU has SHA extensions, else (0, 0) = all on the device.  zk_merkle_commit hands over its tree top
- * in the same way; the field hash always runs on the device.  Results are identical for every setting. */
+/* Division of the latency-bound end of zk_prove* between device and host.  A Merkle level is a chain of dependent
+ * hashes (merkle.rs:40-46): ~4.6 us on a GPU wave (2 293 issue slots of 4 cycles at the ~2.1 GHz the chip holds), ~31 ns
+ * per node on a CPU core with SHA extensions.  With top_log = H > 0 the device builds every SHA-256 tree with more than
+ * 2^H leaves down to its 2^H nodes of depth H (a smaller tree: one level below its leaves) and the host hashes the nodes
+ * above: the calling thread alone for H <= 8, a team of 2^(H-8) threads (one 256-digest sub-tree each, the workers spin
+ * between the commitments of a proof) for H = 9, 10.  With tail_log = T > 0, FRI layers of <= 2^T values
+ * (polynomial.rs:385 fold + merkle.rs:14 tree) are computed by the calling thread as well.  Everything the host built
+ * is copied into the device arrays before the call returns, so zk_layer_read / zk_merkle_path see complete trees.
+ * Default: (8, 9) when the CPU has SHA extensions, else (0, 0) = all on the device (H, T <= 10; T > 0 needs H > 0).
+ * zk_merkle_commit hands over its tree top in the same way; the field hash always runs on the device.  Results are
+ * identical for every setting. */
 int zk_ctx_set_host_levels(zk_ctx *ctx, uint32_t top_log, uint32_t tail_log);
 int zk_ctx_get_host_levels(const zk_ctx *ctx, uint32_t *top_log, uint32_t *tail_log);
 /* The HIP stream every stage is enqueued on (hipStream_t). */
@@ -285,7 +287,7 @@ typedef struct zk_shard_transport {
 typedef struct zk_shard_options {   /* zero = default */
     uint32_t min_layer_log;     /* a FRI layer stays sharded while it has >= 2^this values in total (22) */
     uint32_t min_chunk_log;     /* ... and >= 2^this leaves per (rank, peer) piece (14) */
-    uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (22) */
+    uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (21) */
     int force_collectives;      /* run the collectives even with world = 1 (exercises the transport on one GPU) */
     int no_root_board;          /* exchange subtree roots with an all-gather instead of the shared-memory board */
 } zk_shard_options;

@@ -38,4 +38,4 @@ def test_bench_n2_rehearsal_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["log_n"] == 18
     assert rec["parity_checked"] is True and rec["shard"]["ranks_agree"] is True
     assert rec["shard"]["sharded_layers"] >= 1 and rec["lde_commit_sharded"]["root_stable"] is True
-    assert rec["value"] == pytest.approx(2 * (1 << 21) / (rec["ms_per_step"] * 1e-3), rel=1e-6)
+    assert rec["config"]["domain"] == 1 << 21 and rec["value"] == pytest.approx((1 << 21) / (rec["ms_per_step"] * 1e-3), rel=1e-6)

@@ -446,7 +446,9 @@ def test_compose_and_fold_edge_challenges(zk, orc):
     (10, 3, (0, 0)), (10, 3, (8, 9)), (10, 3, (8, 8)), (10, 3, (5, 5)), (10, 3, (6, 10)), (10, 3, (10, 10)), (10, 3, (8, 0)),
     (10, 3, (3, 3)), (10, 3, (1, 1)), (10, 3, (2, 4)),
     (5, 3, (8, 9)), (6, 3, (8, 9)), (7, 2, (8, 9)), (6, 2, (8, 8)), (4, 1, (3, 4)), (2, 1, (1, 1)),
-    (15, 3, (8, 9)), (15, 3, (0, 0)), (15, 3, (10, 10)), (16, 2, (7, 9)), (17, 3, (8, 9)), (18, 1, (9, 9)), (11, 5, (8, 9))])
+    (15, 3, (8, 9)), (15, 3, (0, 0)), (15, 3, (10, 10)), (16, 2, (7, 9)), (17, 3, (8, 9)), (18, 1, (9, 9)), (11, 5, (8, 9)),
+    # hand-over depths 9 and 10: a team of 2 / 4 threads reduces the tree tops; the host tail may be smaller than the top
+    (15, 3, (10, 9)), (17, 3, (9, 9)), (18, 2, (10, 8)), (12, 3, (10, 0)), (10, 3, (8, 7)), (9, 2, (10, 4)), (17, 3, (10, 9))])
 def test_prover_host_levels_identical(zk, orc, log_n, log_b, levels):
     """Whatever part of the tree tops / small FRI layers the host thread takes over, the proof is the
     oracle's, and the device arrays afterwards hold the complete trees and layers (merkle.rs:14-79)."""
@@ -469,7 +471,7 @@ def test_prover_host_levels_identical(zk, orc, log_n, log_b, levels):
 
 
 def test_host_levels_argument_checks(zk):
-    for bad in ((11, 11), (8, 7), (0, 5), (3, 12)):
+    for bad in ((11, 11), (0, 5), (3, 12), (11, 0)):
         with pytest.raises(zk.ZkError):
             zk.Context(6, 2, host_levels=bad).close()
     # the field hash always builds on the device, whatever the setting

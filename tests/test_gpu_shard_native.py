@@ -163,3 +163,19 @@ def test_config4_native_sharded_lde_transpose_commit_2e26(zk, orc):
         assert root == want_root and again == want_root, f"rank {rank}"
         assert head == [int(want_f[rank + world * j]) for j in range(4)]
         assert st["chunked_layers"] == 1 and st["all_to_all_bytes"] == 4.0 * (1 << 26) / world / world
+
+
+def test_shard_from_plain_c(tmp_path, orc):
+    """The sharded prover reached from a C program (gcc + pthreads, no Python/torch in the process): RCCL is loaded by
+    the library at run time; the proof equals zk_prove's and the oracle's."""
+    import subprocess
+    exe = str(tmp_path / "shard_c_abi")
+    subprocess.check_call(["gcc", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "shard_c_abi.c"),
+                           "-L" + os.path.join(ROOT, "zkstark_amd"), "-lzkstark_amd", "-Wl,-rpath," + os.path.join(ROOT, "zkstark_amd"), "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, "1", "12", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = orc.prove(12, 3, want_vectors=False)
+    assert f"world 1: {len(want.proof)} proof bytes on every rank, equal to zk_prove" in out.stdout
+    assert "native rccl 1" in out.stdout
+    assert "proof head: " + " ".join(f"{b:02x}" for b in want.proof[:8]) in out.stdout

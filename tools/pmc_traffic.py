@@ -7,29 +7,51 @@ on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming 
 doubled (checked here on ntt_pass_kernel<1>, which reads 4 * 2^24 B and reports 32 MiB);
 WRITE_SIZE is exact for streaming stores.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 profiles/traffic.json
+The output is stamped with the commit and the library build hash it was collected from (bench.py prints the
+stamp next to roofline.traffic, so a stale file is visible in the line itself).
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 profiles/traffic.json [commit]
 """
 import collections
 import csv
 import glob
 import json
+import os
+import subprocess
 import sys
+import time
 
 
-def load(d, counter):
-    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
+def load(dirs, counter):
+    """dirs: one directory or several separated by commas (e.g. the bench run and the --staged-only run)."""
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for d in dirs.split(","):
+        for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
+    if commit is None:
+        try:
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except OSError:
+            commit = None
+    sys.path.insert(0, root)
+    try:
+        from zkstark_amd import build as zbuild
+        build_hash = zbuild.source_hash()
+    except Exception:                      # noqa: BLE001
+        build_hash = None
     F, W = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
     res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --steps 1 --warmup 1`; "
-                      "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over all launches of the kernel", "kernels": {}}
+                      "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over all launches of the kernel",
+           "commit": commit, "build_hash": build_hash, "collected": time.strftime("%Y-%m-%d"), "kernels": {}}
     for k in sorted(set(F) | set(W)):
         if not k.startswith(("void zk::", "zk::")):
             continue

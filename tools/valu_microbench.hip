@@ -31,31 +31,35 @@ struct WaveRec { unsigned long long cycles, real; uint32_t hw_id, xcc_id; };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// Every measured instruction is inline assembly: the compiler can neither fold a chain of rotates / adds / xors into
+// one operation nor re-associate it (an earlier version of this file measured folded loops).  ACC independent
+// dependency chains per lane; each instruction reads its own chain's value and a second runtime register.
 template <int OP>
 __global__ __launch_bounds__(256) void bench(uint32_t* out, uint32_t seed, WaveRec* rec) {
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t a[ACC];
+    uint32_t a[ACC], b[ACC];
     float2v pf[ACC];
 #pragma unroll
-    for (int i = 0; i < ACC; ++i) { a[i] = seed * (i + 1) + threadIdx.x; pf[i] = float2v{(float)a[i], 1.0f}; }
-    uint32_t k = seed ^ 0x9e3779b9u, m = seed + 77;
+    for (int i = 0; i < ACC; ++i) { a[i] = seed * (i + 1) + threadIdx.x; b[i] = (seed ^ 0x9e3779b9u) * (i + 3) + threadIdx.x * 7; pf[i] = float2v{(float)a[i], 1.0f}; }
     const float2v pk = float2v{1.0001f, 0.9999f}, pm = float2v{0.5f, 0.25f};
+    const float fk = 1.0001f, fm = 0.5f;
 #pragma unroll 1
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) {
-            if (OP == 0) a[i] = __builtin_amdgcn_alignbit(a[i], a[i], 7);             // v_alignbit_b32
-            if (OP == 1) a[i] = a[i] + a[(i + 1) & (ACC - 1)] + k;                     // v_add3_u32
-            if (OP == 2) a[i] = __builtin_amdgcn_bitop3_b32(a[i], k, m, 0x96);         // v_bitop3_b32
-            if (OP == 3) a[i] = a[i] + k;                                               // v_add_u32
-            if (OP == 4) a[i] = a[i] ^ k;                                               // v_xor_b32
-            if (OP == 5) a[i] = (uint32_t)(((uint64_t)a[i] * k) >> 32);                // v_mul_hi_u32
-            if (OP == 6) a[i] = a[i] * k;                                               // v_mul_lo_u32
-            if (OP == 7) { float f = __uint_as_float(a[i]); f = __builtin_fmaf(f, 1.0001f, 0.5f); a[i] = __float_as_uint(f); }  // v_fma_f32
-            if (OP == 8) a[i] = (a[i] << 30) + a[i];                                    // v_lshl_add_u32
-            if (OP == 9) pf[i] = __builtin_elementwise_fma(pf[i], pk, pm);              // v_pk_fma_f32: 2 fp32 FMAs per lane
+            const uint32_t y = b[(i + u) & (ACC - 1)];
+            if (OP == 0) asm volatile("v_alignbit_b32 %0, %1, %2, 7" : "=v"(a[i]) : "v"(a[i]), "v"(y));
+            if (OP == 1) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(y), "v"(b[i]));
+            if (OP == 2) asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(a[i]) : "v"(a[i]), "v"(y), "v"(b[i]));
+            if (OP == 3) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(y));
+            if (OP == 4) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(y));
+            if (OP == 5) asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(y));
+            if (OP == 6) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(y));
+            if (OP == 7) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(fk), "v"(fm));
+            if (OP == 8) asm volatile("v_lshl_add_u32 %0, %1, 30, %2" : "=v"(a[i]) : "v"(a[i]), "v"(y));
+            if (OP == 9) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pf[i]) : "v"(pf[i]), "v"(pk), "v"(pm));
         }
       }
     }

@@ -178,6 +178,18 @@ ZK_SHA_TARGET void reduce_ni(uint32_t* nodes, uint32_t depth) {
     }
 }
 
+// levels depth-1 .. top of the sub-tree below node `sub` of level `top` (sub < 2^top): the part of reduce_ni that one
+// thread of a team takes; the nodes of a sub-tree are contiguous within every level
+ZK_SHA_TARGET void reduce_sub_ni(uint32_t* nodes, uint32_t depth, uint32_t top, size_t sub) {
+    for (uint32_t d = depth; d-- > top;) {
+        const size_t cnt = (size_t)1 << (d - top);
+        const size_t base = ((size_t)1 << d) - 1 + sub * cnt, child = ((size_t)2 << d) - 1 + 2 * sub * cnt;
+        size_t i = 0;
+        for (; i + 2 <= cnt; i += 2) inner_ni_x2(nodes + 8 * (child + 2 * i), nodes + 8 * (base + i));
+        for (; i < cnt; ++i) inner_ni(nodes + 8 * (child + 2 * i), nodes + 8 * (child + 2 * i + 1), nodes + 8 * (base + i));
+    }
+}
+
 // portable compression for CPUs without the SHA extensions
 void compress_generic(uint32_t st[8], const uint32_t blk[16]) {
     uint32_t w[64];
@@ -225,6 +237,16 @@ void host_sha_inner(const uint32_t left[8], const uint32_t right[8], uint32_t ou
     uint32_t pad[16] = {0x80000000u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 512u};
     compress_generic(st, pad);
     memcpy(out, st, 32);
+}
+
+void host_sha_reduce_sub(uint32_t* nodes, uint32_t depth, uint32_t top, size_t sub) {
+    if (g_have_sha) { reduce_sub_ni(nodes, depth, top, sub); return; }
+    for (uint32_t d = depth; d-- > top;) {
+        const size_t cnt = (size_t)1 << (d - top);
+        const size_t base = ((size_t)1 << d) - 1 + sub * cnt, child = ((size_t)2 << d) - 1 + 2 * sub * cnt;
+        for (size_t i = 0; i < cnt; ++i)
+            host_sha_inner(nodes + 8 * (child + 2 * i), nodes + 8 * (child + 2 * i + 1), nodes + 8 * (base + i));
+    }
 }
 
 void host_sha_reduce(uint32_t* nodes, uint32_t depth) {

@@ -25,5 +25,8 @@ void host_sha_inner(const uint32_t left[8], const uint32_t right[8], uint32_t ou
 // Heap levels above a full level: nodes[(2^depth - 1) ..] holds the 2^depth digests of level `depth`
 // (8 words each, heap order as merkle.rs:14-51); fills levels depth-1 .. 0 in place.
 void host_sha_reduce(uint32_t* nodes, uint32_t depth);
+// The same for one sub-tree only: levels depth-1 .. top below node `sub` of level `top` (sub < 2^top).  A team of
+// threads takes one sub-tree each, then one thread finishes with host_sha_reduce(nodes, top).
+void host_sha_reduce_sub(uint32_t* nodes, uint32_t depth, uint32_t top, size_t sub);
 
 }  // namespace zk

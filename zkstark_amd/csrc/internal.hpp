@@ -31,6 +31,7 @@ const char* last_error();
     } while (0)
 
 constexpr uint32_t kMaxQueries = 64;
+constexpr uint32_t kHostTopSingle = 8;                       // hand-over depth one thread reduces alone (255 nodes, ~8 us)
 constexpr uint32_t kMaxHostLog = 10;                         // host_top, host_tail, log_batch <= 10
 constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // after the digests of depth host_top
 constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail

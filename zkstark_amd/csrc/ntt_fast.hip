@@ -137,10 +137,12 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
                 // the slow storage digits of the digit-reversed DIF output are the LOW digits of k
                 const uint32_t log_n = p.prep_log_n, tsh = log_n - LOGR;
                 uint32_t ka = 0, rem = tsh, sh = 0;
-                for (uint32_t d = 0; d + 1 < p.prep_nd; ++d) {
-                    rem -= p.prep_bits[d];
-                    ka |= ((a >> rem) & ((1u << p.prep_bits[d]) - 1u)) << sh;
-                    sh += p.prep_bits[d];
+#pragma unroll                                                     // constant indices: the argument struct stays in SGPRs (no scratch copy)
+                for (uint32_t d = 0; d + 1 < (uint32_t)kMaxDigits; ++d) {
+                    const uint32_t bits = d + 1 < p.prep_nd ? p.prep_bits[d] : 0u;
+                    rem -= bits;
+                    ka |= ((a >> rem) & ((1u << bits) - 1u)) << sh;
+                    sh += bits;
                 }
                 const uint32_t n1 = (1u << log_n) - 1u;
                 const uint32_t k0 = ka | (tb << tsh), kstep = (uint32_t)RB << tsh;

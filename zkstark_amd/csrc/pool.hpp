@@ -28,6 +28,7 @@ class Pool {
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
+    unsigned workers() const { return (unsigned)th_.size(); }
     template <class F>
     void run(size_t n, size_t grain, F&& fn) {
         if (th_.empty() || n <= grain) { for (size_t i = 0; i < n; ++i) fn(i); return; }

@@ -27,6 +27,7 @@
 #include "transcript.hpp"
 #include "host_sha.hpp"
 #include "internal.hpp"
+#include "pool.hpp"
 
 using namespace zk;
 using namespace zk::impl;
@@ -59,6 +60,9 @@ struct zk_ctx {
     // Host-finished pieces of the one-call prover (host_sha.hpp): the top `host_top` levels of every tree
     // with more than 2^host_top leaves, and whole FRI layers of <= 2^host_tail values (fold + tree).
     uint32_t host_top = 0, host_tail = 0;
+    // hand-over depths above kHostTopSingle are reduced by a small team: 2^(host_top - 8) sub-trees of 256 digests, one
+    // per thread (workers spin between the commitments of a proof), then the calling thread hashes the levels above
+    Pool* pool = nullptr;
     uint32_t* h_stage = nullptr;        // pinned, device-mapped: host-built nodes / values waiting for scatter_kernel
     uint32_t* d_stage = nullptr;
     size_t stage_words = 0, stage_used = 0;
@@ -123,7 +127,9 @@ int do_lde(zk_ctx* c) {
 
 // How much of tree `tree` the host finishes: the top `host_top` levels of SHA-256 trees larger than that.
 uint32_t top_of(const zk_ctx* c, uint32_t tree) {
-    return (c->hash == 0 && c->host_top && layer_log(c, tree) > c->host_top) ? c->host_top : 0;
+    if (c->hash != 0 || !c->host_top) return 0;
+    const uint32_t lg = layer_log(c, tree);
+    return lg > c->host_top ? c->host_top : lg - 1;                 // a smaller tree hands over one level below its leaves
 }
 // What the commit launch of `tree` posts to the host.  host = true (one-call flows): the digests of depth
 // host_top instead of the root, and for the layer with 2^(host_tail+1) values the values too -- the host
@@ -209,7 +215,13 @@ int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
     if (rc) return rc;
     double t0 = now_us();
     memcpy(nodes + 8 * (cnt - 1), c->h_mailbox + kMailDigests, cnt * 32);
-    host_sha_reduce(nodes, H);
+    if (H > kHostTopSingle && c->pool) {
+        const uint32_t top = H - kHostTopSingle;               // 2^top sub-trees of 2^8 digests: ~8 us each, in parallel
+        c->pool->run((size_t)1 << top, 1, [&](size_t sub) { host_sha_reduce_sub(nodes, H, top, sub); });
+        host_sha_reduce(nodes, top);
+    } else {
+        host_sha_reduce(nodes, H);
+    }
     digest_words_to_bytes(nodes, root);
     c->t_host_hash += now_us() - t0;
     if (c->tail_have && c->tail_log == layer_log(c, tree) && tree >= 1) {     // this launch dumped its leaves (mail_of)
@@ -423,6 +435,16 @@ uint32_t zk_field_order(uint32_t a) {
 uint32_t zk_field_root_of_unity(uint32_t log_order) { return log_order > 30 ? 0 : root_of_unity(log_order); }
 
 static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool tail, zk_ctx** out);
+// the team that reduces hand-over depths above kHostTopSingle (none needed at or below it)
+static int ctx_team(zk_ctx* c) {
+    const unsigned want = c->host_top > kHostTopSingle ? (1u << (c->host_top - kHostTopSingle)) - 1u : 0u;
+    if (c->pool && c->pool->workers() == want) return ZK_OK;
+    delete c->pool;
+    c->pool = nullptr;
+    if (!want) return ZK_OK;
+    c->pool = new (std::nothrow) Pool(want);
+    return c->pool ? (int)ZK_OK : fail(ZK_ERR_NOMEM, "out of host memory");
+}
 
 int zk_ctx_create(int device, uint32_t log_n, uint32_t log_b, zk_ctx** out) {
     if (!out) return fail(ZK_ERR_INVALID, "zk_ctx_create: out is null");
@@ -497,8 +519,9 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
         c->host_tail = 9;
         if (const char* e = getenv("ZK_HOST_TOP_LOG")) c->host_top = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 8;
         if (const char* e = getenv("ZK_HOST_TAIL_LOG")) c->host_tail = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 9;
-        if (!c->host_top || c->host_tail < c->host_top) c->host_tail = 0;
+        if (!c->host_top) c->host_tail = 0;
     }
+    if (int prc = ctx_team(c)) { zk_ctx_destroy(c); return prc; }
 #undef HIPCHK_C
     c->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = c;
@@ -523,6 +546,7 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (c->h_mailbox) (void)hipHostFree(c->h_mailbox);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     collect_kernel_stats(c);
+    delete c->pool;
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -547,11 +571,11 @@ int zk_ctx_set_queries(zk_ctx* c, uint32_t n_queries) {
 
 int zk_ctx_set_host_levels(zk_ctx* c, uint32_t top_log, uint32_t tail_log) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
-    if (top_log > kMaxHostLog || tail_log > kMaxHostLog || (tail_log && tail_log < top_log) || (tail_log && !top_log))
-        return fail(ZK_ERR_INVALID, "zk_ctx_set_host_levels: need top_log <= tail_log <= %u (or tail_log = 0)", kMaxHostLog);
+    if (top_log > kMaxHostLog || tail_log > kMaxHostLog || (tail_log && !top_log))
+        return fail(ZK_ERR_INVALID, "zk_ctx_set_host_levels: need top_log, tail_log <= %u, and top_log > 0 when tail_log > 0", kMaxHostLog);
     c->host_top = top_log;
     c->host_tail = tail_log;
-    return ZK_OK;
+    return ctx_team(c);
 }
 int zk_ctx_get_host_levels(const zk_ctx* c, uint32_t* top_log, uint32_t* tail_log) {
     if (!c || !top_log || !tail_log) return fail(ZK_ERR_INVALID, "zk_ctx_get_host_levels: null argument");
@@ -609,17 +633,28 @@ int zk_lde(zk_ctx* c) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
     if (!c->have_trace) return fail(ZK_ERR_STATE, "zk_lde: no trace uploaded");
     HIPCHK(hipSetDevice(c->device));
-    return do_lde(c);
+    static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
+    const double t0 = now_us();
+    int rc = do_lde(c);
+    if (timing) fprintf(stderr, "[zk timing] lde: enqueue of %u passes %.1f us\n", 2 * c->dom->plan.nd + (c->log_n > kFusePrepMaxLogN ? 1 : 0), now_us() - t0);
+    return rc;
 }
 
 int zk_merkle_commit(zk_ctx* c, uint32_t layer, uint8_t root_out[32]) {
     if (!c || !root_out) return fail(ZK_ERR_INVALID, "zk_merkle_commit: null argument");
     if (layer > c->R + 1) return fail(ZK_ERR_INVALID, "zk_merkle_commit: layer %u out of range", layer);
     HIPCHK(hipSetDevice(c->device));
+    static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
+    const double t0 = now_us();
     begin_proof(c);                                      // a stand-alone commitment: nothing staged, no host-side FRI tail
     int rc = do_merkle(c, layer, true, false);           // Merkle::new (merkle.rs:14); the last levels on this thread
+    const double t1 = now_us();
     if (!rc) rc = read_commit(c, layer, root_out);
+    const double t2 = now_us();
     if (!rc) rc = flush_host_parts(c);                   // the tree in HBM is complete before any later stage reads it
+    if (timing)
+        fprintf(stderr, "[zk timing] merkle_commit(layer %u): enqueue %.1f us, wait for the device %.1f us, host top %.1f us, scatter enqueue %.1f us\n",
+                layer, t1 - t0, c->t_wait, c->t_host_hash, now_us() - t2);
     return rc;
 }
 
