@@ -131,8 +131,8 @@ def cpu_baseline(sample_log_n, log_b):
                                 "seconds": dt_naive, "value": 8192 / dt_naive, "unit": "field-elements/s"},
         "value": N / dt_all, "unit": "field-elements/s", "cores": cores, "kind": "port",
         "nproc": nproc, "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
-        "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads "
-                  f"(nproc = {nproc}, host logical CPUs = {os.cpu_count()}), {dt_all:.2f} s",
+        "sample": f"oracle full prover (NTT mode), domain 2^{sample_log_n + log_b}, {cores} OpenMP threads = every core this process "
+                  f"may use (nproc = {nproc}, host logical CPUs = {os.cpu_count()}, cgroup CPU quota = {quota if quota else 'none'}), {dt_all:.2f} s",
         "single_thread_value": (N // 8) / dt_one,
         "single_thread_sample": f"domain 2^{sample_log_n + log_b - 3}, 1 thread, {dt_one:.2f} s",
     }

@@ -466,7 +466,10 @@ __device__ __forceinline__ Digest lds_digest(const uint4* p) {
 template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src, uint32_t* nodes,
                                                                         uint32_t depth_in, uint32_t k, size_t off) {
-    // per wave: k levels x 2 groups x 64 digests x 2 uint4
+    // per wave: k pending LEFT sibling groups (one per level) + one scratch group for the right sibling of the
+    // pairing in progress, 64 digests x 2 uint4 each = (k + 1) x 2 KiB.  (Keeping left and right per level would
+    // be 4 KiB per level: at k = 4 that is 64 KiB per workgroup and two waves per SIMD; the SHA-256 instruction mix
+    // issues ~10 % faster with four or more, tools/valu_mix_probe.hip.)
     extern __shared__ __attribute__((aligned(16))) uint4 stage[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const size_t gwave = (size_t)blockIdx.x * (kMerkleThreads / 64) + wave;
@@ -474,7 +477,8 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
     // tree): a chunk is an aligned sub-range of the leaves, built into its place in the heap
     const size_t base = (gwave << (6 + k)) + off;
     const size_t in_base = ((size_t)1 << depth_in) - 1;
-    uint4* my = stage + (size_t)wave * k * 256;
+    uint4* my = stage + (size_t)wave * (k + 1) * 128;
+    uint4* scratch = my + (size_t)k * 128;
 #pragma unroll 1
     for (uint32_t i = 0; i < (1u << k); ++i) {
         Digest d;
@@ -488,13 +492,15 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
         uint32_t idx = i, lvl = 0;
 #pragma unroll 1
         while (lvl < k) {                                        // wave-uniform
-            uint4* grp = my + (lvl * 2 + (idx & 1u)) * 128;
+            uint4* left = my + lvl * 128;
+            uint4* grp = (idx & 1u) ? scratch : left;
             grp[2 * lane] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
             grp[2 * lane + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
             if (!(idx & 1u)) break;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint4* x = my + lvl * 256 + 4 * lane;          // children 2*lane, 2*lane+1 of the 128 buffered nodes
+            // children 2*lane, 2*lane+1 of the 128 buffered nodes: lanes 0-31 pair the left group, lanes 32-63 the right
+            const uint4* x = (lane < 32u ? left : scratch - 128) + 4 * lane;
             Digest l = lds_digest(x), r = lds_digest(x + 2);
             __builtin_amdgcn_wave_barrier();
             d = Hasher<HASH>::inner(l, r);
@@ -681,6 +687,14 @@ static hipError_t ensure_fieldhash_consts() {
 // i.e. while there are more than ~4 waves per SIMD to keep busy.  Latency phase: workgroup launches
 // of up to 10 levels each.
 constexpr uint32_t kMerkleLatencyLogDefault = 17;   // measured flat optimum 16..18 (profiles/README.md)
+static uint32_t merkle_max_k() {                  // ZK_MERKLE_MAX_K overrides (tuning only): levels per subtree launch
+    static const uint32_t v = [] {
+        const char* e = getenv("ZK_MERKLE_MAX_K");
+        uint32_t x = e ? (uint32_t)atoi(e) : kMerkleMaxK;
+        return (x < 1 || x > kMerkleMaxK) ? kMerkleMaxK : x;
+    }();
+    return v;
+}
 static uint32_t merkle_latency_log() {            // ZK_MERKLE_LATENCY_LOG overrides (tuning only)
     static const uint32_t v = [] {
         const char* e = getenv("ZK_MERKLE_LATENCY_LOG");
@@ -716,10 +730,10 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
     const uint32_t floor_depth = throughput_only ? kMerkleLatencyLog : stop + kMerkleLatencyLog;
     while (depth > floor_depth) {
         uint32_t k = depth - floor_depth;
-        if (k > kMerkleMaxK) k = kMerkleMaxK;
+        if (k > merkle_max_k()) k = merkle_max_k();
         size_t lanes = (size_t)1 << (depth - stop - k);         // >= 2^17: a multiple of the block size
         uint32_t blocks = (uint32_t)(lanes / kMerkleThreads);
-        size_t sh = (size_t)(kMerkleThreads / 64) * k * 256 * sizeof(uint4);
+        size_t sh = (size_t)(kMerkleThreads / 64) * (k + 1) * 128 * sizeof(uint4);
         ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, first_bytes(merkle_bytes(leaf, depth - stop, k)), s, merkle_ops(leaf, depth - stop, k, hash));
         if (hash) {
             if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k, off_at(depth));

@@ -74,10 +74,12 @@ enum NttMode : uint32_t {
     NTT_DIT_LDE = 2,    // first forward pass of the LDE: reads n prepared coefficients, writes N = n*B values
 };
 
-// Workgroup tile of an NTT pass, in words: 8192 for big transforms (HBM-bound: long row segments), 2048 once a pass
-// has fewer than ~1000 big tiles (latency-bound: more workgroups, fewer elements per thread).
+// Workgroup tile of an NTT pass, in words: 8192 for big transforms (long row segments: HBM traffic 1.00-1.03 x the
+// algorithmic bytes), 2048 for passes over <= 2^20 words (latency-bound: 4 x the workgroups, a quarter of the elements
+// per thread).  At 2^21 the small tile was 12 % faster but fetched 2 x the bytes (64-byte row segments at radix 128,
+// PMC FETCH_SIZE), so the switch sits below that size.
 constexpr uint32_t kBigTileLog = 13, kSmallTileLog = 11;
-inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total >= kBigTileLog + 10 ? kBigTileLog : kSmallTileLog; }
+inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total > 20 ? kBigTileLog : kSmallTileLog; }
 
 struct NttPassArgs {
     const uint32_t* src;
