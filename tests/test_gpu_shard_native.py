@@ -149,19 +149,16 @@ def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
             assert st["chunked_layers"] >= 2
 
 
-def test_config4_native_sharded_lde_transpose_commit_2e26(zk, orc):
+def test_config4_native_sharded_lde_transpose_commit_2e26(zk, config4_expected):
     """configs[3]: domain 2^26, each of 2 ranks evaluates its cosets (no communication), one all-to-all
     transposes to natural order (chunked, overlapped with the hashing), subtrees + host top.  The root is the
     CPU oracle's (orc.lde + orc.merkle_build), the shards are the oracle's values at i = rank (mod 2)."""
-    log_n, world = 23, 2
-    a = zk.trace_fibsq((1 << log_n) - 1)
-    orc.set_threads(os.cpu_count() or 1)
-    want_f = orc.lde(a, log_n, 3)
-    want_root = bytes(orc.merkle_build(want_f)[0])
+    log_n, world = config4_expected["log_n"], 2
+    want_root, want_head = config4_expected["root"], config4_expected["head"]
     out = _run(world, log_n, 3, {}, "lde_commit", timeout=1200)
     for rank, root, again, head, st in out:
         assert root == want_root and again == want_root, f"rank {rank}"
-        assert head == [int(want_f[rank + world * j]) for j in range(4)]
+        assert head == [int(want_head[rank + world * j]) for j in range(4)]
         assert st["chunked_layers"] == 1 and st["all_to_all_bytes"] == 4.0 * (1 << 26) / world / world
 
 

@@ -167,18 +167,13 @@ def _config4_worker(rank, world, port, log_n, q):
         dist.destroy_process_group()
 
 
-def test_config4_sharded_lde_and_transpose_domain_2e26(zk, orc):
+def test_config4_sharded_lde_and_transpose_domain_2e26(zk, config4_expected):
     """configs[3] through the torch.distributed mirror (zkstark_amd/sharded.py): domain 2^26 evaluated by 2 ranks
     (each its cosets, no communication), all-to-all transpose to natural order, subtree commitment; the root and
     the shards equal the CPU oracle's (orc.lde + orc.merkle_build)."""
     import torch.multiprocessing as mp
-    log_n, world = 23, 2
-    a = zk.trace_fibsq((1 << log_n) - 1)
-    orc.set_threads(os.cpu_count() or 1)
-    head_all = orc.lde(a, log_n, 3)
-    want_root = bytes(orc.merkle_build(head_all)[0])
-    head = head_all[:4 * world].copy()
-    del head_all
+    log_n, world = config4_expected["log_n"], 2
+    want_root, head = config4_expected["root"], config4_expected["head"]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mctx = mp.get_context("spawn")
     q = mctx.Queue()
