@@ -12,11 +12,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by a cgroup CPU quota (a GPU box shows 256 logical
+    CPUs and allows 16: an OpenMP team of 256 threads on 16 cores' worth of quota crawls)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                n = min(n, max(1, math.ceil(int(q) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (oracle/): the checker, never the thing under test on the GPU side."""
     import oracle
     oracle.lib()
+    oracle.set_threads(usable_cores())
     return oracle
 
 
@@ -34,7 +50,6 @@ def config4_expected(orc):
     import numpy as np
     log_n = 23
     a = orc.trace_fibsq((1 << log_n) - 1)
-    orc.set_threads(os.cpu_count() or 1)
     f = orc.lde(a, log_n, 3)
     root = bytes(orc.merkle_build(f)[0])
     head = np.array(f[:64], dtype=np.uint32)
