@@ -91,6 +91,7 @@ def spawn_ranks(args):
 
 def host_cores():
     """Cores this process may use: the affinity mask (what `nproc` prints), capped by a cgroup CPU quota."""
+    import oracle
     aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = None
     try:
@@ -100,7 +101,7 @@ def host_cores():
                 quota = max(1, math.ceil(int(q) / int(period)))
     except (OSError, ValueError):
         pass
-    return (min(aff, quota) if quota else aff), aff, quota
+    return oracle.usable_cores(), aff, quota
 
 
 def cpu_baseline(sample_log_n, log_b):

@@ -40,6 +40,21 @@ class _Debug(C.Structure):
 _lib = None
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by a cgroup CPU quota.  (A GPU box shows 256 logical
+    CPUs and grants 16: OpenMP's default team of 256 threads then runs several times slower than 16 threads.)"""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                n = min(n, max(1, math.ceil(int(q) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -85,6 +100,7 @@ def lib():
         L.orc_proof_size.restype = sz; L.orc_proof_size.argtypes = [sz]
         L.orc_proof_data_len.restype = sz; L.orc_proof_data_len.argtypes = [u32, u32]
         _lib = L
+        L.orc_set_threads(usable_cores())      # not OpenMP's default (every logical CPU, whatever the quota)
     return _lib
 
 

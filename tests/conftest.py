@@ -12,27 +12,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def usable_cores():
-    """Cores this process may really use: the affinity mask capped by a cgroup CPU quota (a GPU box shows 256 logical
-    CPUs and allows 16: an OpenMP team of 256 threads on 16 cores' worth of quota crawls)."""
-    import math
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, period = f.read().split()
-            if q != "max":
-                n = min(n, max(1, math.ceil(int(q) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (oracle/): the checker, never the thing under test on the GPU side."""
     import oracle
     oracle.lib()
-    oracle.set_threads(usable_cores())
+    oracle.set_threads(oracle.usable_cores())
     return oracle
 
 
