@@ -62,10 +62,13 @@ def main():
                              "hbm_bytes_per_launch": fb + wb}
     # the dominant kernel class of bench.py: every leaf-mode instantiation of merkle_subtree_kernel
     # (plain, fused-fold and fused-compose sources), averaged over all of their launches
-    leaf = [k for k in set(F) | set(W) if "merkle_subtree_kernel<" in k and ", true," in k]
-    nl = sum(len(W.get(k, [])) for k in leaf)
+    # ... of the FIRST directory of each list only (the `bench.py --steps 1 --warmup 1` run): the same launch population
+    # as the bench line's algorithmic_bytes_per_launch; the --staged-only run has a different mix of leaf launches
+    F1, W1 = load(fetch.split(",")[0], "FETCH_SIZE"), load(write.split(",")[0], "WRITE_SIZE")
+    leaf = [k for k in set(F1) | set(W1) if "merkle_subtree_kernel<" in k and ", true," in k]
+    nl = sum(len(W1.get(k, [])) for k in leaf)
     if nl:
-        tot = sum(2.0 * sum(F.get(k, [])) + sum(W.get(k, [])) for k in leaf) * 1024
+        tot = sum(2.0 * sum(F1.get(k, [])) + sum(W1.get(k, [])) for k in leaf) * 1024
         res["merkle_leaf_bytes_per_launch"] = tot / nl
         res["merkle_leaf_launches_seen"] = nl
     json.dump(res, open(out, "w"), indent=1)
