@@ -149,6 +149,20 @@ def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
             assert st["chunked_layers"] >= 2
 
 
+def test_shard_two_ranks_production_sizes_2e25(orc):
+    """Two ranks at the per-rank size of the weak-scaling benchmark (2^24 elements each, domain 2^25) with the
+    production thresholds: f, cp and two FRI layers go through the chunked exchange (pieces of 2^23 .. 2^21 words), the
+    rest through single exchanges and the replicated tail.  Every byte of the proof and all 24 roots against the oracle."""
+    log_n, world = 22, 2
+    want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
+    assert want.rc == 0
+    out = _run(world, log_n, 3, {}, "prove", timeout=1200)
+    for rank, data, state, roots, st in out:
+        assert data == want.proof and state == want.state, f"rank {rank}"
+        assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
+        assert st["sharded_layers"] == 4 and st["chunked_layers"] == 4 and st["root_board"] == 1
+
+
 def test_config4_native_sharded_lde_transpose_commit_2e26(zk, config4_expected):
     """configs[3]: domain 2^26, each of 2 ranks evaluates its cosets (no communication), one all-to-all
     transposes to natural order (chunked, overlapped with the hashing), subtrees + host top.  The root is the
