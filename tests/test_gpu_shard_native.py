@@ -163,6 +163,22 @@ def test_shard_two_ranks_production_sizes_2e25(orc):
         assert st["sharded_layers"] == 4 and st["chunked_layers"] == 4 and st["root_board"] == 1
 
 
+def test_shard_four_ranks_production_sizes_2e26(orc):
+    """Four ranks, 2^24 elements each (domain 2^26, the size of BASELINE.json configs[3]), production thresholds:
+    chunked exchange for pieces of 2^22 and 2^21 words, single exchanges below, replicated tail from 2^21 values."""
+    log_n, world = 23, 4
+    want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
+    assert want.rc == 0
+    out = _run(world, log_n, 3, {}, "prove", timeout=1200)
+    N = 1 << (log_n + 3)
+    for rank, data, state, roots, st in out:
+        assert data == want.proof and state == want.state, f"rank {rank}"
+        assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
+        assert st["sharded_layers"] == 5 and st["chunked_layers"] == 3 and st["root_board"] == 1
+        words = N + sum(N >> rho for rho in range(5))
+        assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world      # 12 N-ish bytes in total, (G-1)/G of it to peers
+
+
 def test_config4_native_sharded_lde_transpose_commit_2e26(zk, config4_expected):
     """configs[3]: domain 2^26, each of 2 ranks evaluates its cosets (no communication), one all-to-all
     transposes to natural order (chunked, overlapped with the hashing), subtrees + host top.  The root is the
