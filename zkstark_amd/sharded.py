@@ -1,4 +1,7 @@
-"""Sharded prover: one proof across G GPUs of one node (one process per GPU, RCCL over xGMI).
+"""Sharded prover over torch.distributed: the CPU-testable MIRROR of the native sharded prover (csrc/shard.hip,
+zk_shard_*), which is what bench.py and non-Python callers use.  Same protocol, same thresholds, same bytes.
+
+One proof across G GPUs of one node (one process per GPU, RCCL over xGMI).
 
 Layout.  The evaluation domain is distributed CYCLICALLY: rank r holds the
 elements i = r (mod G) of every layer.  Rank r's shard of the size-N coset {w h^i} is itself a
@@ -753,66 +756,3 @@ def staged_transport(group=None):
             return 1
 
     return _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(all_to_all), _lib.ALL_GATHER_FN(all_gather))
-
-
-def bench(args, rank, local_rank, world, barrier, staged=False, force=False):
-    """bench.py leg for N > 1: one proof over `world` GPUs at domain 2^(log_n + log_blowup) * world
-    (weak scaling: per-GPU work equals the single-GPU workload)."""
-    lg = world.bit_length() - 1
-    log_n = args.log_n + lg
-    comm = Comm(staged=staged, force=force)
-    be = HipBackend(local_rank)
-    t0 = time.perf_counter()
-    sp = ShardedProver(log_n, args.log_blowup, comm, be)
-    be.sync()
-    setup_ms = (time.perf_counter() - t0) * 1e3
-    trace = trace_fibsq((1 << log_n) - 1)
-    sp.trace_upload(trace)
-    lib = _lib.load()
-    # No silent retry: a failure of the chunked list exchange or of the root board is a defect to look at, not a
-    # reason to measure something else.  --plain-collectives (ZK_SHARD_PLAIN=1) selects the plain path explicitly.
-    conservative = os.environ.get("ZK_SHARD_PLAIN") == "1"
-    sp.prove()
-
-    def stats():
-        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
-        check(lib.zk_dev_kernel_stats(arr, len(arr), 1))
-        return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes, "ops": a.ops} for name, a in zip(_lib.KERNEL_CLASSES, arr)}
-
-    for _ in range(args.warmup):
-        proof = sp.prove()
-    lib.zk_dev_set_profiling(1 << _lib.KERNEL_CLASSES.index("merkle_leaf"))   # dominant kernel only
-    stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = sp.prove()
-    barrier()
-    dt = time.perf_counter() - t0
-    dom = stats()["merkle_leaf"]
-    if rank == 0:
-        proof.verify()
-    lib.zk_dev_set_profiling((1 << len(_lib.KERNEL_CLASSES)) - 1)
-    sp.prove()
-    per_kernel = stats()
-    lib.zk_dev_set_profiling(0)
-    N = 1 << (log_n + args.log_blowup)
-    # secondary figure, BASELINE.json configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit only
-    lde_commit = None
-    if not getattr(args, "no_secondary", False):
-        root0 = sp.lde_commit()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            root1 = sp.lde_commit()
-        barrier()
-        dtl = (time.perf_counter() - t0) / 5
-        lde_commit = {"workload": f"configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit, domain 2^{log_n + args.log_blowup} over {world} GPUs",
-                      "ms": dtl * 1e3, "value": N / dtl, "unit": "field-elements/s", "root_stable": root0 == root1}
-    res = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": setup_ms, "device_bytes": 0, "lde_commit_sharded": lde_commit,
-           "proof_bytes": len(proof.data), "scaling": "weak", "units": N * args.steps,
-           "parallelism": f"one proof sharded over {world} GPUs (cyclic domain, all-to-all per commitment)" +
-                          (", plain collectives only" if conservative else ""),
-           "log_n": log_n}
-    sp.close()
-    return res
