@@ -1,0 +1,120 @@
+/* shard_threads_check.c -- the native sharded prover with `world` ranks as THREADS of one process on one GPU
+ * (tests/test_gpu_shard_native.py).  A one-GPU box allows only a handful of processes on the card, so this is how
+ * world = 8 (lg = 3: the full top path, local blow-up 1, eight-way all-to-all) is exercised natively; it is also the
+ * threading model of examples/shard_c_abi.c.  The transport is the caller's (include/zkstark_amd.h:
+ * zk_shard_transport): peers publish their send pointers, a barrier, device-to-device copies, a barrier.
+ *   gcc -O2 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/shard_threads_check.c \
+ *       -Lzkstark_amd -lzkstark_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/zkstark_amd -Wl,-rpath,/opt/rocm/lib -o shard_threads_check
+ *   ./shard_threads_check world log_n log_blowup min_layer_log min_chunk_log overlap_min_log
+ */
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "zkstark_amd.h"
+
+#define MAXW 16
+static int g_world;
+static pthread_barrier_t g_bar;
+static const uint32_t *const *g_send[MAXW];   /* rank r's send pointer table for the exchange in progress */
+static const uint32_t *g_gather[MAXW];
+
+typedef struct { int rank; } tp_user;
+
+static int tp_all_to_all(void *user, const uint32_t *const *send, uint32_t *const *recv, size_t words, void *stream) {
+    const int me = ((tp_user *)user)->rank;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;   /* my send pieces are complete */
+    g_send[me] = send;
+    pthread_barrier_wait(&g_bar);
+    int bad = 0;
+    for (int q = 0; q < g_world; ++q)   /* piece `me` of rank q's table comes to my recv[q] */
+        if (hipMemcpyAsync(recv[q], g_send[q][me], words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) bad = 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) bad = 1;
+    pthread_barrier_wait(&g_bar);       /* nobody reuses a send buffer before every peer has read it */
+    return bad;
+}
+static int tp_all_gather(void *user, const uint32_t *send, uint32_t *recv, size_t words, void *stream) {
+    const int me = ((tp_user *)user)->rank;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+    g_gather[me] = send;
+    pthread_barrier_wait(&g_bar);
+    int bad = 0;
+    for (int q = 0; q < g_world; ++q)
+        if (hipMemcpyAsync(recv + (size_t)q * words, g_gather[q], words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) bad = 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) bad = 1;
+    pthread_barrier_wait(&g_bar);
+    return bad;
+}
+
+typedef struct {
+    int rank, rc;
+    uint32_t log_n, log_b;
+    zk_shard_options opt;
+    const uint8_t *id;
+    const uint32_t *trace;
+    uint8_t *proof, state[32], root[32];
+    size_t cap, len;
+    zk_shard_stats stats;
+    char err[256];
+} rank_args;
+
+static void *run_rank(void *p) {
+    rank_args *a = p;
+    tp_user u = {a->rank};
+    zk_shard_transport tp = {&u, tp_all_to_all, tp_all_gather};
+    zk_shard *sp = NULL;
+    a->rc = zk_shard_create(0, a->rank, g_world, a->id, &tp, &a->opt, a->log_n, a->log_b, &sp);
+    if (!a->rc) a->rc = zk_shard_trace_upload(sp, a->trace, ((size_t)1 << a->log_n) - 1);
+    if (!a->rc) a->rc = zk_shard_prove(sp, a->proof, a->cap, &a->len, a->state);
+    if (!a->rc) a->rc = zk_shard_get_stats(sp, &a->stats);
+    if (!a->rc) a->rc = zk_shard_lde_commit(sp, a->root);
+    if (a->rc) snprintf(a->err, sizeof a->err, "%s", zk_last_error());
+    zk_shard_destroy(sp);
+    return NULL;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 7) { fprintf(stderr, "usage: world log_n log_blowup min_layer_log min_chunk_log overlap_min_log\n"); return 2; }
+    g_world = atoi(argv[1]);
+    const uint32_t log_n = (uint32_t)atoi(argv[2]), log_b = (uint32_t)atoi(argv[3]);
+    if (g_world < 1 || g_world > MAXW) return 2;
+    pthread_barrier_init(&g_bar, NULL, (unsigned)g_world);
+    const size_t n = (size_t)1 << log_n, cap = zk_proof_data_len(log_n, log_b);
+    uint32_t *trace = malloc((n - 1) * sizeof *trace);
+    if (zk_trace_fibsq(1, 3141592, n - 1, trace)) return 1;
+    uint8_t id[ZK_SHARD_ID_BYTES];
+    for (int i = 0; i < ZK_SHARD_ID_BYTES; ++i) id[i] = (uint8_t)(rand() ^ (i * 37));   /* names the root board */
+    rank_args args[MAXW];
+    pthread_t th[MAXW];
+    for (int r = 0; r < g_world; ++r) {
+        memset(&args[r], 0, sizeof args[r]);
+        args[r].rank = r; args[r].log_n = log_n; args[r].log_b = log_b; args[r].id = id; args[r].trace = trace;
+        args[r].opt.min_layer_log = (uint32_t)atoi(argv[4]); args[r].opt.min_chunk_log = (uint32_t)atoi(argv[5]);
+        args[r].opt.overlap_min_log = (uint32_t)atoi(argv[6]);
+        args[r].cap = cap; args[r].proof = malloc(cap);
+        pthread_create(&th[r], NULL, run_rank, &args[r]);
+    }
+    for (int r = 0; r < g_world; ++r) pthread_join(th[r], NULL);
+    for (int r = 0; r < g_world; ++r)
+        if (args[r].rc) { fprintf(stderr, "rank %d: %d: %s\n", r, args[r].rc, args[r].err); return 1; }
+    /* the single-GPU prover on the same trace: every rank's proof must be byte-identical to it */
+    zk_ctx *ctx = NULL;
+    uint8_t *one = malloc(cap), st1[32], root1[32];
+    size_t len1 = 0;
+    if (zk_ctx_create(0, log_n, log_b, &ctx) || zk_prove(ctx, trace, n - 1, one, cap, &len1, st1) || zk_lde(ctx) || zk_merkle_commit(ctx, 0, root1)) {
+        fprintf(stderr, "%s\n", zk_last_error());
+        return 1;
+    }
+    zk_ctx_destroy(ctx);
+    for (int r = 0; r < g_world; ++r) {
+        if (args[r].len != len1 || memcmp(args[r].proof, one, len1) || memcmp(args[r].state, st1, 32)) { fprintf(stderr, "rank %d: proof differs from zk_prove\n", r); return 1; }
+        if (memcmp(args[r].root, root1, 32)) { fprintf(stderr, "rank %d: lde_commit root differs\n", r); return 1; }
+    }
+    if (zk_verify_strict(one, len1, st1, log_n, log_b, trace[n - 2])) { fprintf(stderr, "%s\n", zk_last_error()); return 1; }
+    printf("threads ok: world %d, %zu proof bytes on every rank equal zk_prove; sharded layers %u, chunked %u, board %u, all-to-all bytes per rank %.0f\n",
+           g_world, len1, args[0].stats.sharded_layers, args[0].stats.chunked_layers, args[0].stats.root_board, args[0].stats.all_to_all_bytes);
+    return 0;
+}

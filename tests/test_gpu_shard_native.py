@@ -206,3 +206,53 @@ def test_shard_from_plain_c(tmp_path, orc):
     assert f"world 1: {len(want.proof)} proof bytes on every rank, equal to zk_prove" in out.stdout
     assert "native rccl 1" in out.stdout
     assert "proof head: " + " ".join(f"{b:02x}" for b in want.proof[:8]) in out.stdout
+
+
+@pytest.fixture(scope="module")
+def threads_check(tmp_path_factory):
+    import subprocess
+    exe = str(tmp_path_factory.mktemp("shard") / "shard_threads_check")
+    subprocess.check_call(["gcc", "-O2", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "shard_threads_check.c"), "-L" + os.path.join(ROOT, "zkstark_amd"), "-lzkstark_amd",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "zkstark_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("world,log_n,log_b,thresholds", [
+    (8, 14, 3, (1, 5, 8)),        # lg = 3: local blow-up 1, three-digest top paths, chunked f / cp / first FRI layer
+    (8, 17, 3, (16, 6, 12)),      # ... with a replicated tail that starts early
+    (16, 14, 4, (1, 4, 9)),       # lg = 4
+    (2, 13, 3, (1, 5, 9)),
+    (4, 15, 2, (1, 5, 9)),
+])
+def test_shard_ranks_as_threads_of_one_process(threads_check, orc, world, log_n, log_b, thresholds):
+    """world = 8 and 16 natively on one GPU: the ranks are threads of one C process (the model of
+    examples/shard_c_abi.c) with a device-to-device transport; every rank's proof equals zk_prove's (checked inside the
+    harness) and the oracle's."""
+    import subprocess
+    out = subprocess.run([threads_check, str(world), str(log_n), str(log_b)] + [str(t) for t in thresholds],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = orc.prove(log_n, log_b, want_vectors=False)
+    assert f"threads ok: world {world}, {len(want.proof)} proof bytes on every rank equal zk_prove" in out.stdout
+    assert "board 1" in out.stdout
+
+
+def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
+    """The exact configuration `bench.py --gpus 8` proves: domain 2^27, eight ranks of 2^24 elements each, production
+    thresholds (0 = defaults) -- here as eight threads on one GPU.  Every rank's bytes equal the single-GPU prover's at
+    2^27 (itself oracle-pinned up to 2^24 and by the strict verifier here); 6 distributed layers, f and cp chunked."""
+    import subprocess
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 10**9:
+        pytest.skip("needs 80 GB of free device memory")
+    out = subprocess.run([threads_check, "8", "24", "3", "0", "0", "0"], capture_output=True, text=True, timeout=1100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    from zkstark_amd import _lib
+    plen = _lib.load().zk_proof_data_len(24, 3)
+    assert f"threads ok: world 8, {plen} proof bytes on every rank equal zk_prove; sharded layers 6, chunked 2, board 1" in out.stdout
+    # 12 N-ish bytes in total: f and FRI layers 0..5, 4 bytes per element, (G-1)/G of it to peers
+    N = 1 << 27
+    words = N + sum(N >> rho for rho in range(6))
+    assert f"all-to-all bytes per rank {4.0 * words / 8 * 7 / 8:.0f}" in out.stdout
