@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "zkstark_amd.h"
 
@@ -58,8 +59,16 @@ typedef struct {
     uint8_t *proof, state[32], root[32];
     size_t cap, len;
     zk_shard_stats stats;
+    int reps;               /* extra timed proofs (argv[7]); the time shows the TOTAL device work of all ranks on one GPU */
+    double ms_per_proof;
     char err[256];
 } rank_args;
+
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
 
 static void *run_rank(void *p) {
     rank_args *a = p;
@@ -70,6 +79,13 @@ static void *run_rank(void *p) {
     if (!a->rc) a->rc = zk_shard_trace_upload(sp, a->trace, ((size_t)1 << a->log_n) - 1);
     if (!a->rc) a->rc = zk_shard_prove(sp, a->proof, a->cap, &a->len, a->state);
     if (!a->rc) a->rc = zk_shard_get_stats(sp, &a->stats);
+    if (!a->rc && a->reps > 0) {
+        pthread_barrier_wait(&g_bar);
+        const double t0 = now_ms();
+        for (int i = 0; i < a->reps && !a->rc; ++i) a->rc = zk_shard_prove(sp, a->proof, a->cap, &a->len, a->state);
+        pthread_barrier_wait(&g_bar);
+        a->ms_per_proof = (now_ms() - t0) / a->reps;
+    }
     if (!a->rc) a->rc = zk_shard_lde_commit(sp, a->root);
     if (a->rc) snprintf(a->err, sizeof a->err, "%s", zk_last_error());
     zk_shard_destroy(sp);
@@ -95,6 +111,7 @@ int main(int argc, char **argv) {
         args[r].opt.min_layer_log = (uint32_t)atoi(argv[4]); args[r].opt.min_chunk_log = (uint32_t)atoi(argv[5]);
         args[r].opt.overlap_min_log = (uint32_t)atoi(argv[6]);
         args[r].cap = cap; args[r].proof = malloc(cap);
+        args[r].reps = argc > 7 ? atoi(argv[7]) : 0;
         pthread_create(&th[r], NULL, run_rank, &args[r]);
     }
     for (int r = 0; r < g_world; ++r) pthread_join(th[r], NULL);
@@ -114,6 +131,18 @@ int main(int argc, char **argv) {
         if (memcmp(args[r].root, root1, 32)) { fprintf(stderr, "rank %d: lde_commit root differs\n", r); return 1; }
     }
     if (zk_verify_strict(one, len1, st1, log_n, log_b, trace[n - 2])) { fprintf(stderr, "%s\n", zk_last_error()); return 1; }
+    if (args[0].reps > 0) {
+        /* the same domain on the one-call prover, for the ratio (total work of the sharded run / work of one proof) */
+        zk_ctx *c2 = NULL;
+        if (!zk_ctx_create(0, log_n, log_b, &c2) && !zk_trace_upload(c2, trace, n - 1) && !zk_prove_resident(c2, one, cap, &len1, st1)) {
+            const double t0 = now_ms();
+            for (int i = 0; i < args[0].reps; ++i) zk_prove_resident(c2, one, cap, &len1, st1);
+            const double single = (now_ms() - t0) / args[0].reps;
+            printf("timing: %d ranks sharing the GPU %.2f ms per proof (all ranks' device work, serialised) = %.2f ms per rank; one-call prover %.2f ms\n",
+                   g_world, args[0].ms_per_proof, args[0].ms_per_proof / g_world, single);
+        }
+        zk_ctx_destroy(c2);
+    }
     printf("threads ok: world %d, %zu proof bytes on every rank equal zk_prove; sharded layers %u, chunked %u, board %u, all-to-all bytes per rank %.0f\n",
            g_world, len1, args[0].stats.sharded_layers, args[0].stats.chunked_layers, args[0].stats.root_board, args[0].stats.all_to_all_bytes);
     return 0;
