@@ -105,7 +105,7 @@ struct zk_shard {
     ncclComm_t comm = nullptr;
     bool force = false;                                // collectives even with G = 1
     // layout
-    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 21;
+    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 22;
     static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
     uint32_t n_sharded = 1, tail_rounds = 0;
     zk_dom* dom_loc = nullptr;
