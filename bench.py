@@ -420,6 +420,8 @@ def main():
             "kernel": "merkle_subtree_kernel<leaf>", "bound": "hbm",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic if (args.hash == "sha256" and not sharded_run) else None, "traffic_stamp": traffic_stamp,
+            # True when the PMC passes behind `traffic` were collected from the very build that ran this line
+            "traffic_from_this_build": bool(traffic_stamp) and traffic_stamp.get("build_hash") == _lib.build_hash(),
             "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
             "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
             "note": "SHA-256 is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu{}; stages[] lists the HBM-bound kernels",
