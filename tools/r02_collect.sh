@@ -3,7 +3,7 @@
 # traffic.json / valu_utilization.json from the PMC passes.  Run in the build container after the GPU call.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/r02h; P=profiles
+O=gpurun_out/r02h; P=profiles   # (clear $O before tools/r02_final.sh: gpurun merges new files next to old ones)
 cp $O/valu_microbench.txt $P/r02_valu_microbench.txt; cp $O/sha_latency_probe.txt $P/r02_sha_latency_probe.txt; cp $O/valu_mix_probe.txt $P/r02_valu_mix_probe.txt
 cp $O/bench.json $P/r02_bench_2e24.json; cp $O/bench_sharded_1rank.json $P/r02_bench_sharded_1rank.json
 cp $O/bench_rehearsal_n2.json $P/r02_bench_rehearsal_n2.json; cp $O/bench_rehearsal_n4.json $P/r02_bench_rehearsal_n4.json
