@@ -32,10 +32,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-# 32-bit VALU: 64 lanes/clk/CU measured for every op SHA-256 uses, at 1/2/4/8 waves per SIMD
-# (tools/valu_microbench.hip, profiles/r02_valu_microbench.txt): 256 CUs x 64 lanes x 2.4 GHz = 39.3 T lane-ops/s.
-VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12
-SHA_LEAF_OPS, SHA_INNER_OPS = 1259, 2293
+# 32-bit VALU issue model, measured per op at 1/2/4/8 waves per SIMD (tools/valu_microbench.hip,
+# profiles/r02_valu_microbench.txt): a wave64 instruction occupies its SIMD for 4 cycles (v_alignbit, v_add3, v_mul_*,
+# v_lshl_add) or 2 cycles (v_bitop3, v_add_u32, v_xor, shifts, v_cndmask, v_sub_co; only when several waves share the SIMD).
+NOMINAL_GHZ, SIMDS = 2.4, 256 * 4
+VALU_PEAK_4CYC_TOPS = SIMDS * 64 * NOMINAL_GHZ * 1e9 / 4 / 1e12          # 39.3 T lane-ops/s if every op took 4 cycles
+# Per hash: VALU instructions (ISA count, tools/kernel_descriptors.py; tests/test_kernel_descriptors.py pins them against
+# the built code object) and the 4-cycle share of the mix, which gives the mix-weighted issue peak.
+HASH_MODEL = {
+    "sha256": {"leaf_ops": 1259, "inner_ops": 2293, "probe_ops": 2246, "four_cycle_share": (940 + 365) / 2262.0},
+    # field hash: dynamic count = 4 x full-round loop + 22 x partial-round loop + 4 x full-round loop + straight-line rest
+    "field": {"leaf_ops": 12550, "inner_ops": 12567, "probe_ops": 12567, "four_cycle_share": 0.45},
+}
+def mix_peak_tops(hash_name):
+    """Issue peak for this hash's instruction mix at the nominal clock: lanes / (mean cycles per instruction)."""
+    f4 = HASH_MODEL[hash_name]["four_cycle_share"]
+    return SIMDS * 64 * NOMINAL_GHZ * 1e9 / (4 * f4 + 2 * (1 - f4)) / 1e12
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (stamped with its commit)
 
 
@@ -332,6 +344,31 @@ def main():
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": ctx.setup_ms,
                   "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
                   "units": N * args.steps, "parallelism": "single-gpu", "host_levels": list(ctx.host_levels)}
+        # the same proofs with everything on the device (host_levels (0, 0): no tree tops, no FRI tail on the host thread)
+        if args.hash == "sha256" and tuple(ctx.host_levels) != (0, 0):
+            keep = tuple(ctx.host_levels)
+            ctx.set_host_levels(0, 0)
+            for _ in range(2):
+                dproof = ctx.prove()
+            reps = min(args.steps, 20)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dproof = ctx.prove()
+            barrier()
+            result["device_only"] = {"ms_per_step": (time.perf_counter() - t0) / reps * 1e3, "steps": reps, "host_levels": [0, 0],
+                                     "same_proof": dproof.data == proof.data and dproof.state == proof.state}
+            ctx.set_host_levels(*keep)
+        # roofline probe: the compiled inner hash in a dependent chain, >= 10 launches back to back, at the residency of
+        # the subtree kernels (SHA-256: 8 waves per SIMD) and at half of it; the clock is read, not assumed
+        hm = HASH_MODEL[args.hash]
+        chain = []
+        for wps in ((4, 8) if args.hash == "sha256" else (1, 2, 3)):
+            pr = zk.probe_hash_chain(args.hash, waves_per_simd=wps, hashes=16 if args.hash == "sha256" else 4, launches=12, device=local_rank)
+            chain.append({"waves_per_simd": wps, "ns_per_instr": pr["ns_per_hash_per_simd"] / hm["probe_ops"], "clock_ghz": round(pr["clock_ghz"], 3),
+                          "cycles_per_instr": pr["ns_per_hash_per_simd"] / hm["probe_ops"] * pr["clock_ghz"], "launches": pr["launches"],
+                          "launch_ms": pr["ms"] / pr["launches"]})
+        result["chain"] = chain
         # soak: keep the device busy for a few seconds (driver-side sampling sees it; steady-state figure)
         if args.soak_seconds > 0:
             t0 = time.perf_counter()
@@ -352,7 +389,7 @@ def main():
                 for _ in range(50):
                     c2.lde(); c2.merkle_commit(0)
                 dt2 = (time.perf_counter() - t0) / 50
-            floor_us = ((1 << 20) * SHA_LEAF_OPS + ((1 << 20) - 1) * SHA_INNER_OPS) / (VALU_PEAK_TOPS * 1e12) * 1e6
+            floor_us = ((1 << 20) * HASH_MODEL['sha256']['leaf_ops'] + ((1 << 20) - 1) * HASH_MODEL['sha256']['inner_ops']) / (VALU_PEAK_4CYC_TOPS * 1e12) * 1e6
             result["lde_commit_2e20"] = {"workload": "configs[1]: domain 2^20 LDE + Merkle commit", "us": dt2 * 1e6,
                                          "value": (1 << 20) / dt2, "unit": "field-elements/s",
                                          "valu_floor_us": floor_us, "frac_of_valu_floor": floor_us / (dt2 * 1e6),
@@ -416,22 +453,47 @@ def main():
         dom = result["dom"]
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
         traffic, traffic_stamp = traffic_record()
+        hm = HASH_MODEL[args.hash]
+        valu_ach = dom["ops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0            # T lane-ops/s
+        mix_peak = mix_peak_tops(args.hash)
+        # the kernel's own issue rate: wave-instructions per SIMD per ns (ops are lane-ops: / 64 lanes / 1024 SIMDs)
+        kernel_ns_per_instr = dom["ms"] * 1e6 / (dom["ops"] / 64 / SIMDS) if dom["ops"] else None
+        chain = result.get("chain") or []
+        best_chain = min((c["ns_per_instr"] for c in chain), default=None)
+        valu = {"achieved": valu_ach, "unit": "T lane-ops/s (32-bit)",
+                "peak_mix_weighted": mix_peak, "frac_of_mix_peak": valu_ach / mix_peak,
+                "peak_all_4_cycle": VALU_PEAK_4CYC_TOPS, "frac_of_4_cycle_peak": valu_ach / VALU_PEAK_4CYC_TOPS,
+                "ops_per_leaf_hash": hm["leaf_ops"], "ops_per_inner_hash": hm["inner_ops"], "four_cycle_share": round(hm["four_cycle_share"], 4),
+                "kernel_ns_per_instr": kernel_ns_per_instr,
+                "chain": chain, "chain_ns_per_instr": best_chain,
+                "frac_of_chain": (best_chain / kernel_ns_per_instr) if (best_chain and kernel_ns_per_instr) else None,
+                "peak_basis": "mix-weighted: 1024 SIMDs x 64 lanes x 2.4 GHz / (4 f4 + 2 (1 - f4)) cycles, f4 = share of 4-cycle ops in the hash "
+                              "(profiles/r02_valu_microbench.txt); chain: zk_probe_hash_chain, the compiled inner hash in a dependent chain, "
+                              "12 launches back to back, clock read from s_memtime / s_memrealtime"}
         roofline = {
-            "kernel": "merkle_subtree_kernel<leaf>", "bound": "hbm",
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "kernel": "merkle_subtree_kernel<leaf>" if args.hash == "sha256" else "merkle_subtree_fh_kernel<leaf>",
+            "bound": "valu",
+            "achieved": valu_ach, "peak": mix_peak, "unit": "T lane-ops/s", "frac": valu_ach / mix_peak,
             "traffic": traffic if (args.hash == "sha256" and not sharded_run) else None, "traffic_stamp": traffic_stamp,
             # True when the PMC passes behind `traffic` were collected from the very build that ran this line
             "traffic_from_this_build": bool(traffic_stamp) and traffic_stamp.get("build_hash") == _lib.build_hash(),
             "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-            "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
-            "note": "SHA-256 is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu{}; stages[] lists the HBM-bound kernels",
-            "valu": {"achieved": dom["ops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0, "peak": VALU_PEAK_TOPS,
-                     "unit": "T lane-ops/s (32-bit)",
-                     "frac": (dom["ops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS) if dom["ms"] > 0 else 0.0,
-                     "ops_per_leaf_hash": SHA_LEAF_OPS if args.hash == "sha256" else 10200,
-                     "ops_per_inner_hash": SHA_INNER_OPS if args.hash == "sha256" else 10300,
-                     "peak_basis": "64 lanes/clk/CU x 256 CUs x 2.4 GHz; measured at 1/2/4/8 waves per SIMD (profiles/r02_valu_microbench.txt)"},
+            "note": "integer-VALU bound (SURVEY.md 8d): frac is against the mix-weighted issue peak at the nominal clock; valu.frac_of_chain is "
+                    "against the measured steady-state rate of the compiled hash; hbm{} is the same launches against the HBM roofline; "
+                    "stages[] lists the HBM-bound kernels",
+            "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1)},
+            "valu": valu,
         }
+        # the hashing of one proof against its floor: every Merkle launch of the per-stage proof, and the time the same
+        # instruction count needs at the chain rate (a floor the kernels cannot beat by construction)
+        pk = result["per_kernel"]
+        hash_ms = sum(pk[k]["ms"] for k in ("merkle_leaf", "merkle_inner") if k in pk)
+        hash_ops = sum(pk[k]["ops"] for k in ("merkle_leaf", "merkle_inner") if k in pk)
+        if best_chain and hash_ops:
+            floor_ms = hash_ops / 64 / SIMDS * best_chain * 1e-6
+            roofline["hashing"] = {"ms_per_proof": hash_ms, "floor_ms_at_chain_rate": floor_ms, "frac": floor_ms / hash_ms if hash_ms else None,
+                                   "wave_instructions_per_simd": hash_ops / 64 / SIMDS}
         stages = []
         def add_stage(name, st, note=None):
             if st["launches"]:
@@ -439,7 +501,7 @@ def main():
                 row = {"kernel": name, "launches": st["launches"], "ms": round(st["ms"], 4),
                        "algorithmic_GB": round(st["bytes"] / 1e9, 4), "GBps": round(gbs, 1),
                        "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                       "valu_frac": round(st["ops"] / (st["ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4) if st["ms"] > 0 and st["ops"] else None}
+                       "valu_frac_of_mix_peak": round(st["ops"] / (st["ms"] * 1e-3) / 1e12 / mix_peak, 4) if st["ms"] > 0 and st["ops"] and "merkle" in name else None}
                 if note:
                     row["note"] = note
                 stages.append(row)
@@ -452,7 +514,8 @@ def main():
             "metric": "field-elements/s through LDE+Merkle+FRI (full STARK-101 prover)",
             "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": result["scaling"], "vs_baseline": None, "dtype": "u32 (mod 3*2^30+1) + SHA-256",
+            "scaling": result["scaling"], "vs_baseline": None,
+            "dtype": "u32 (mod 3*2^30+1) + SHA-256" if args.hash == "sha256" else "u32 (mod 3*2^30+1), field-native Merkle hash",
             "data": "synthetic Fibonacci-square trace (a0=1, a1=3141592), deterministic",
             "config": {"workload": f"full prover: LDE + compose + FRI + Merkle, domain 2^{log_n + log_b} "
                                    f"(trace group 2^{log_n}, blow-up {1 << log_b})" + (f" per proof; {result['parallelism']}" if world > 1 else ""),
@@ -465,7 +528,7 @@ def main():
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],
             "proof_bytes": result["proof_bytes"], "build_hash": _lib.build_hash(),
         }
-        for k in ("pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "shard"):
+        for k in ("device_only", "pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "shard"):
             if result.get(k) is not None:
                 out[k] = result[k]
         if sharded_run:
@@ -483,6 +546,20 @@ def main():
                     print("[bench] PARITY FAILURE: the timed proof differs from the CPU oracle's", file=sys.stderr, flush=True)
             else:
                 out["parity_checked"] = False
+        if world == 1 and not sharded_run and not args.no_cpu_baseline and args.hash == "field":
+            # configs[4]: the hash is the build's own definition, the checker is the oracle's independent plain-residue
+            # implementation, too slow for 10^8 nodes: byte comparison at domain 2^16, the verifier on the timed proof
+            import oracle
+            oracle.set_hash(oracle.HASH_FIELD)
+            oracle.set_threads(host_cores()[0])
+            want = oracle.prove(13, log_b, want_vectors=False)
+            oracle.set_hash(oracle.HASH_SHA256)
+            with zk.Context(13, log_b, device=local_rank, hash="field") as cs:
+                got = cs.prove(zk.trace_fibsq((1 << 13) - 1))
+            ok = want.rc == 0 and got.data == want.proof and got.state == want.state
+            out["parity_checked"] = bool(ok)
+            out["parity"] = {"against": f"CPU oracle (field hash, independent implementation): full proof bytes + channel state at domain 2^{13 + log_b}; "
+                                        f"the timed 2^{log_n + log_b} proof passed zk_verify_ex(hash=field)", "equal": bool(ok)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if out.get("parity_checked") is False and out.get("parity", {}).get("equal") is False:

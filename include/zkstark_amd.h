@@ -326,6 +326,21 @@ int zk_shard_get_stats(const zk_shard *s, zk_shard_stats *out);
 int zk_dev_set_profiling(uint32_t class_mask);
 int zk_dev_kernel_stats(zk_kernel_stat *out, size_t count, int reset);
 
+/* Roofline probe (measurement only; bench.py `roofline.valu.chain_*`): every lane of waves_per_simd resident waves per
+ * SIMD runs a dependent chain of `hashes` inner hashes (merkle.rs:42-45 shape) with no memory traffic, `launches`
+ * launches back to back.  ns_per_hash_per_simd is the steady-state time one SIMD needs per hash of one wave; divided
+ * by the hash's VALU instruction count it is the issue rate the Merkle kernels can reach at best at that residency. */
+typedef struct zk_chain_probe {
+    double ns_per_hash_per_simd;
+    double clock_ghz;              /* median over the waves: shader clocks per 100 MHz reference tick */
+    double ms;                     /* wall time of the timed launches (HIP events) */
+    uint32_t waves_per_simd;
+    uint32_t launches;
+    uint32_t hashes;
+    uint32_t cus;                  /* compute units of the device */
+} zk_chain_probe;
+int zk_probe_hash_chain(int device, int hash_kind, uint32_t waves_per_simd, uint32_t hashes, uint32_t launches, zk_chain_probe *out);
+
 /* ---- stand-alone primitives on host buffers (upload, run on the GPU, download) -- */
 /* Merkle::new(size, data) (merkle.rs:14): nodes_out = (2m-1)*32 bytes, heap order. */
 int zk_merkle_build_host(int device, const uint32_t *vals, size_t m, uint8_t *nodes_out);

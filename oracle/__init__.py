@@ -86,6 +86,7 @@ def lib():
         L.orc_fri_fold_eval.restype = None; L.orc_fri_fold_eval.argtypes = [vp, u32, u32, u32, u32, vp]
         L.orc_sha256.restype = None; L.orc_sha256.argtypes = [vp, sz, vp]
         L.orc_merkle_build.restype = C.c_int; L.orc_merkle_build.argtypes = [vp, sz, vp]
+        L.orc_node_hash.restype = None; L.orc_node_hash.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
         L.orc_merkle_trace.restype = sz; L.orc_merkle_trace.argtypes = [vp, sz, sz, vp]
         L.orc_compute_root_from_path.restype = None
         L.orc_compute_root_from_path.argtypes = [u32, sz, vp, sz, vp]
@@ -247,6 +248,13 @@ def merkle_build(vals):
     if rc:
         raise ValueError("merkle size must be a power of two")
     return nodes
+
+
+def node_hash(left: bytes, right: bytes) -> bytes:
+    """merkle.rs:42-45 for one pair of 32-byte digests (the hash selected by set_hash)."""
+    out = C.create_string_buffer(32)
+    lib().orc_node_hash(bytes(left), bytes(right), out)
+    return out.raw
 
 
 def merkle_trace(nodes, leaf):

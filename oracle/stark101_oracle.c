@@ -680,6 +680,9 @@ static void node_hash(const uint8_t *l, const uint8_t *r, uint8_t out[32]) {
     orc_sha256(cat, 64, out);
 }
 
+/* merkle.rs:42-45 for one pair (tests: the levels above a set of device-built nodes) */
+void orc_node_hash(const uint8_t *l, const uint8_t *r, uint8_t out[32]) { node_hash(l, r, out); }
+
 /* merkle.rs:14-51 Merkle::new */
 int orc_merkle_build(const uint32_t *vals, size_t m, uint8_t *nodes) {
     if (m == 0 || (m & (m - 1))) return -1;          /* merkle.rs:16-21 assert */

@@ -88,6 +88,8 @@ void orc_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
 int orc_merkle_build(const uint32_t *vals, size_t m, uint8_t *nodes);
 /* Merkle::trace (merkle.rs:54-71): returns path length (log2 m). */
 size_t orc_merkle_trace(const uint8_t *nodes, size_t m, size_t leaf, uint8_t *path_out);
+/* merkle.rs:42-45: parent of one pair of digests, with the hash selected by orc_set_hash */
+void orc_node_hash(const uint8_t *l, const uint8_t *r, uint8_t out[32]);
 /* compute_root_from_path (merkle.rs:82-110). */
 void orc_compute_root_from_path(uint32_t element, size_t index, const uint8_t *path,
                                 size_t path_len, uint8_t out[32]);

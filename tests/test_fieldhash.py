@@ -80,3 +80,62 @@ def test_fieldhash_full_size_properties(zk):
     assert half[0] == m[1]
     assert zk.compute_root_from_path(int(vals[777]), 777, m.trace(777), hash="field") == m[0]
     assert all(int.from_bytes(m[0][4 * i:4 * i + 4], "big") < P for i in range(8))
+
+
+@pytest.mark.gpu
+def test_fieldhash_prover_matches_oracle_domain_2e21(zk, field_oracle):
+    """The largest full-proof comparison the oracle's plain-residue hash affords (12.6 M hashes: ~15 s on 16 cores)."""
+    log_n, log_b = 18, 3
+    want = field_oracle.prove(log_n, log_b, want_vectors=False)
+    with zk.Context(log_n, log_b, hash="field") as ctx:
+        proof = ctx.prove(zk.trace_fibsq((1 << log_n) - 1))
+    assert proof.data == want.proof and proof.state == want.state
+    proof.verify()
+
+
+@pytest.mark.gpu
+def test_config5_fieldhash_full_prover_domain_2e24(zk, field_oracle):
+    """BASELINE.json configs[4] at its stated size: domain 2^24, Merkle hash = the field-native hash.
+    The oracle's hash is too slow for 10^8 nodes, so at this size: the proof verifies; proving is idempotent; the
+    committed f_eval layer equals the SHA-256 prover's (the hash does not touch the arithmetic); for the f_eval and
+    cp trees the 4096 nodes of depth 12 reduce to the root with the ORACLE's hash and sampled depth-12 subtrees
+    (4096 leaves each, every throughput-kernel level) equal the oracle's; openings recompute the root."""
+    log_n, log_b = 21, 3
+    N = 1 << (log_n + log_b)
+    trace = zk.trace_fibsq((1 << log_n) - 1)
+    with zk.Context(log_n, log_b, hash="field") as ctx:
+        proof = ctx.prove(trace)
+        proof.verify()
+        info = ctx.last_transcript()
+        again = ctx.prove()
+        assert again.data == proof.data and again.state == proof.state
+        f_digest = hashlib.sha256(ctx.layer_read(0).tobytes()).hexdigest()
+        rng = np.random.default_rng(2024)
+        for tree in (0, 1):
+            root = ctx.merkle_node(tree, 0)
+            assert root == bytes(info.roots[tree])
+            lvl = [ctx.merkle_node(tree, (1 << 12) - 1 + j) for j in range(1 << 12)]
+            # top 12 levels with the oracle's node hash
+            cur = lvl
+            while len(cur) > 1:
+                cur = [field_oracle.node_hash(cur[2 * j], cur[2 * j + 1]) for j in range(len(cur) // 2)]
+            assert cur[0] == root
+            # sampled subtrees below depth 12, leaves included
+            for j in [0, 4095] + [int(x) for x in rng.integers(1, 4095, size=6)]:
+                vals = ctx.layer_read(tree, j << 12, 1 << 12)
+                sub = field_oracle.merkle_build(vals)
+                assert bytes(sub[0]) == lvl[j], (tree, j)
+                leaf = int(rng.integers(0, 1 << 12))
+                path = ctx.merkle_path(tree, (j << 12) + leaf)
+                assert zk.compute_root_from_path(int(vals[leaf]), (j << 12) + leaf, path, hash="field") == root
+        # a deep FRI layer too (fold fused into the leaf hashing of the field-hash kernel)
+        for tree in (2, 5, 9):
+            m = ctx.layer_size(tree)
+            x = int(rng.integers(0, m))
+            v = int(ctx.layer_read(tree, x, 1)[0])
+            assert zk.compute_root_from_path(v, x, ctx.merkle_path(tree, x), hash="field") == bytes(info.roots[tree])
+    with zk.Context(log_n, log_b) as sha_ctx:          # same arithmetic, other hash: identical committed values
+        sha_ctx.trace_upload(trace)
+        sha_ctx.lde()
+        assert hashlib.sha256(sha_ctx.layer_read(0).tobytes()).hexdigest() == f_digest
+    assert N == 1 << 24

@@ -50,6 +50,11 @@ class ShardStats(C.Structure):
                 ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double)]
 
 
+class ChainProbe(C.Structure):
+    _fields_ = [("ns_per_hash_per_simd", C.c_double), ("clock_ghz", C.c_double), ("ms", C.c_double),
+                ("waves_per_simd", C.c_uint32), ("launches", C.c_uint32), ("hashes", C.c_uint32), ("cus", C.c_uint32)]
+
+
 KERNEL_CLASSES = ("ntt", "merkle_leaf", "merkle_inner", "merkle_top", "compose", "fri_fold", "gather")
 
 
@@ -158,6 +163,7 @@ SYMBOLS = {
     "zk_shard_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
     "zk_shard_layer_read": (_int, [_vp, _u32, _sz, _sz, _vp]),
     "zk_shard_get_stats": (_int, [_vp, C.POINTER(ShardStats)]),
+    "zk_probe_hash_chain": (_int, [_int, _int, _u32, _u32, _u32, C.POINTER(ChainProbe)]),
     "zk_dev_set_profiling": (_int, [_u32]),
     "zk_dev_kernel_stats": (_int, [_vp, _sz, _int]),
     "zk_dev_merkle_build": (_int, [_vp, _u32, _vp, _vp]),

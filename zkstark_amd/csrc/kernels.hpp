@@ -26,8 +26,10 @@ enum KernelClass : int {
 constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
 constexpr double kShaInnerOps = 2293.0;
 constexpr double kNttOpsPerElement = 78.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU: 2456-2560 per wave of 32 elements/lane)
-constexpr double kFieldLeafOps = 10200.0;   // field-native hash, one permutation (estimate from timing at equal VALU efficiency, +-5 %)
-constexpr double kFieldInnerOps = 10300.0;   // ... of one inner hash (two compressions, second with constant schedule)
+// field-native hash: one permutation per hash.  Dynamic ISA count (tools/kernel_descriptors.py --loops: 4 + 4 trips of the
+// full-round loops, 22 of the partial-round loop, plus the straight-line rest), confirmed by SQ_INSTS_VALU (profiles/)
+constexpr double kFieldLeafOps = 12550.0;
+constexpr double kFieldInnerOps = 12567.0;
 
 struct Profiler {
     uint32_t mask = 0;
@@ -208,6 +210,9 @@ hipError_t launch_fold_merkle_batch(const FoldBatchArgs& a, uint32_t log_batch, 
 // batch traces of prover.rs:32-39, one lane per trace: out[t*stride + i], i < count (stride 0 = count)
 hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint32_t batch, uint32_t count, uint32_t* out, hipStream_t s,
                                     uint32_t stride = 0);
+
+// measurement only: blocks x 256 lanes, each a chain of `hashes` inner hashes; rec (optional): per wave {shader clocks, 100 MHz ticks}
+hipError_t launch_hash_chain_probe(int hash, uint32_t blocks, uint32_t* out, uint32_t seed, uint32_t hashes, unsigned long long* rec, hipStream_t s);
 
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,

@@ -6,6 +6,7 @@
 // Domains and transforms live in domain.hip, the batched prover in batch.hip (shared: internal.hpp).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -1190,6 +1191,50 @@ int zk_merkle_build_host_ex(int device, const uint32_t* vals, size_t m, uint8_t*
     if (rc) return rc;
     for (size_t i = 0; i < 2 * m - 1; ++i) digest_words_to_bytes(host.data() + 8 * i, nodes_out + 32 * i);
     return ZK_OK;
+}
+
+// Roofline probe: the compiled inner hash in a dependent chain, `launches` launches back to back (steady state,
+// no residency tail), waves_per_simd resident waves on every SIMD.  Measurement only.
+int zk_probe_hash_chain(int device, int hash_kind, uint32_t waves_per_simd, uint32_t hashes, uint32_t launches, zk_chain_probe* out) {
+    if (!out || (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) || waves_per_simd < 1 || waves_per_simd > 8 || !hashes || !launches)
+        return fail(ZK_ERR_INVALID, "zk_probe_hash_chain: bad argument");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount, blocks = cus * waves_per_simd;   // one 256-thread workgroup = one wave per SIMD
+    uint32_t* d_out = nullptr;
+    unsigned long long* d_rec = nullptr;
+    HIPCHK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+    hipError_t e = hipMalloc(&d_rec, (size_t)blocks * 4 * 16);
+    if (e != hipSuccess) { (void)hipFree(d_out); return fail(ZK_ERR_NOMEM, "hipMalloc failed"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = ZK_OK;
+    std::vector<unsigned long long> rec((size_t)blocks * 8);
+    do {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipEventCreate failed"); break; }
+        if (launch_hash_chain_probe(hash_kind, blocks, d_out, 3u, hashes, d_rec, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            rc = fail(ZK_ERR_HIP, "probe launch failed"); break;
+        }
+        (void)hipEventRecord(e0, nullptr);
+        for (uint32_t r = 0; r < launches; ++r) (void)launch_hash_chain_probe(hash_kind, blocks, d_out, 12345u + r, hashes, d_rec, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(ZK_ERR_HIP, "probe failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (hipMemcpy(rec.data(), d_rec, rec.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "D2H failed"); break; }
+        std::vector<double> ghz;
+        for (size_t i = 0; i + 1 < rec.size(); i += 2)
+            if (rec[i + 1]) ghz.push_back((double)rec[i] / (double)rec[i + 1] * 0.1);     // s_memrealtime ticks at 100 MHz
+        std::sort(ghz.begin(), ghz.end());
+        out->ms = ms;
+        out->ns_per_hash_per_simd = (double)ms * 1e6 / ((double)launches * waves_per_simd * hashes);
+        out->clock_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
+        out->waves_per_simd = waves_per_simd; out->launches = launches; out->hashes = hashes; out->cus = cus;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_out); (void)hipFree(d_rec);
+    return rc;
 }
 
 int zk_ntt_host(int device, uint32_t* data, uint32_t log_m, int inverse) {

@@ -49,6 +49,14 @@ class field:
     def order(a): return _lib.load().zk_field_order(a)     # field.rs:45-49
 
 
+def probe_hash_chain(hash="sha256", waves_per_simd=4, hashes=16, launches=10, device=0):
+    """Roofline probe (zk_probe_hash_chain): steady-state rate of the compiled inner hash in a dependent chain."""
+    r = _lib.ChainProbe()
+    check(_lib.load().zk_probe_hash_chain(device, HASHES[hash], waves_per_simd, hashes, launches, C.byref(r)))
+    return {"ns_per_hash_per_simd": r.ns_per_hash_per_simd, "clock_ghz": r.clock_ghz, "ms": r.ms,
+            "waves_per_simd": r.waves_per_simd, "launches": r.launches, "hashes": r.hashes, "cus": r.cus}
+
+
 def trace_fibsq(count, a0=1, a1=3141592):
     """prover.rs:32-39."""
     out = np.zeros(count, dtype=np.uint32)
