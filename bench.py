@@ -42,7 +42,7 @@ VALU_PEAK_4CYC_TOPS = SIMDS * 64 * NOMINAL_GHZ * 1e9 / 4 / 1e12          # 39.3 
 HASH_MODEL = {
     "sha256": {"leaf_ops": 1259, "inner_ops": 2293, "probe_ops": 2246, "four_cycle_share": (940 + 365) / 2262.0},
     # field hash: dynamic count = 4 x full-round loop + 22 x partial-round loop + 4 x full-round loop + straight-line rest
-    "field": {"leaf_ops": 12550, "inner_ops": 12567, "probe_ops": 12567, "four_cycle_share": 0.45},
+    "field": {"leaf_ops": 9080, "inner_ops": 9092, "probe_ops": 9092, "four_cycle_share": 0.45},
 }
 def mix_peak_tops(hash_name):
     """Issue peak for this hash's instruction mix at the nominal clock: lanes / (mean cycles per instruction)."""
@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--soak-seconds", type=float, default=3.0,
                     help="after the timed region: keep proving for this long (untimed by the metric; steady-state figure)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=None, help="oracle sample: domain 2^(this+blowup); default: the benchmark's own size")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = domain 2^(log_n + blowup) * N, per-GPU work fixed (default); strong = the single-GPU domain split over N GPUs")
     ap.add_argument("--plain-collectives", action="store_true", help="N > 1: no chunked exchange, no shared-memory root board")
     ap.add_argument("--staged-only", action="store_true", help="run only the stage-by-stage leg (rocprofv3 of compose / fold kernels)")
     return ap.parse_args()
@@ -249,7 +251,8 @@ def main():
         return
     if sharded_run:
         lg = world.bit_length() - 1
-        log_n = args.log_n + lg                              # weak scaling: per-GPU work equals the single-GPU workload
+        # weak scaling: per-GPU work equals the single-GPU workload; strong: the single-GPU domain over all GPUs
+        log_n = args.log_n + (lg if args.scaling == "weak" else 0)
         uid = [zk.shard_unique_id() if (rank == 0 and not staged) else None]
         if staged:
             uid = [os.urandom(128) if rank == 0 else None]
@@ -293,26 +296,44 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, agree[0])
         same_everywhere = all(g == gathered[0] for g in gathered)
+        def time_lde_commit(ctx_, reps=10):
+            root0 = ctx_.lde_commit()
+            barrier()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                root1 = ctx_.lde_commit()
+            barrier()
+            dtl_ = torch.tensor([(time.perf_counter() - t0_) / reps], dtype=torch.float64)
+            dist.all_reduce(dtl_, op=dist.ReduceOp.MAX)
+            return float(dtl_.item()), root0 == root1, ctx_.stats()["all_to_all_bytes"]
         lde_commit = None
-        if not args.no_secondary:                            # BASELINE.json configs[3] shape
-            root0 = sp.lde_commit()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                root1 = sp.lde_commit()
-            barrier()
-            dtl = (time.perf_counter() - t0) / 10
+        config4 = None
+        if not args.no_secondary:                            # BASELINE.json configs[3] shape at the prover's own domain
+            dtl, stable, a2a = time_lde_commit(sp)
             lde_commit = {"workload": f"configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit, domain 2^{log_n + log_b} over {world} GPUs",
-                          "ms": dtl * 1e3, "value": N / dtl, "unit": "field-elements/s", "root_stable": root0 == root1,
-                          "all_to_all_bytes_per_rank": sp.stats()["all_to_all_bytes"]}
+                          "ms": dtl * 1e3, "value": N / dtl, "unit": "field-elements/s", "root_stable": stable,
+                          "all_to_all_bytes_per_rank": a2a}
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": st["setup_ms"], "device_bytes": int(st["device_bytes"]),
-                  "lde_commit_sharded": lde_commit, "proof_bytes": len(proof.data), "scaling": "weak", "units": N * args.steps,
+                  "lde_commit_sharded": lde_commit, "proof_bytes": len(proof.data), "scaling": args.scaling, "units": N * args.steps,
                   "parallelism": f"one proof sharded over {world} GPUs (cyclic domain; native RCCL all-to-all per commitment)" if not staged
                                  else f"REHEARSAL: {world} ranks on one GPU, host-staged collectives",
                   "shard": {**st, "sent_bytes_per_proof_per_rank": st["sent_bytes"], "ranks_agree": same_everywhere,
                             "exchanged_bytes_per_element": st["all_to_all_bytes"] * world / N if world > 1 else 0.0},
                   "parity": parity}
         sp.close()
+        if not args.no_secondary and world in (2, 4, 8) and log_b == 3:
+            # BASELINE.json configs[3] at EXACTLY its size: domain 2^26 (trace group 2^23) over the N GPUs of this run
+            uid2 = [zk.shard_unique_id() if (rank == 0 and not staged) else (os.urandom(128) if rank == 0 else None)]
+            dist.broadcast_object_list(uid2, src=0)
+            with zk.ShardContext(23, 3, rank, world, uid2[0], device=local_rank, transport=transport,
+                                 no_root_board=args.plain_collectives) as sp4:
+                sp4.trace_upload(zk.trace_fibsq((1 << 23) - 1))
+                dtl, stable, a2a = time_lde_commit(sp4)
+                st4 = sp4.stats()
+            config4 = {"workload": f"configs[3]: domain 2^26 NTT (LDE) sharded over {world} GPUs, all-to-all transpose, Merkle commit",
+                       "ms": dtl * 1e3, "value": (1 << 26) / dtl, "unit": "field-elements/s", "root_stable": stable,
+                       "all_to_all_bytes_per_rank": a2a, "rccl_nranks": st4["rccl_nranks"], "chunked_layers": st4["chunked_layers"]}
+            result["config4_2e26"] = config4
         if parity and parity.get("equal") is False:
             print("[bench] sharded proof differs from the single-GPU prover", file=sys.stderr, flush=True)
             sys.exit(4)
@@ -363,7 +384,7 @@ def main():
         # the subtree kernels (SHA-256: 8 waves per SIMD) and at half of it; the clock is read, not assumed
         hm = HASH_MODEL[args.hash]
         chain = []
-        for wps in ((4, 8) if args.hash == "sha256" else (1, 2, 3)):
+        for wps in ((4, 8) if args.hash == "sha256" else (3, 6)):
             pr = zk.probe_hash_chain(args.hash, waves_per_simd=wps, hashes=16 if args.hash == "sha256" else 4, launches=12, device=local_rank)
             chain.append({"waves_per_simd": wps, "ns_per_instr": pr["ns_per_hash_per_simd"] / hm["probe_ops"], "clock_ghz": round(pr["clock_ghz"], 3),
                           "cycles_per_instr": pr["ns_per_hash_per_simd"] / hm["probe_ops"] * pr["clock_ghz"], "launches": pr["launches"],
@@ -528,7 +549,7 @@ def main():
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],
             "proof_bytes": result["proof_bytes"], "build_hash": _lib.build_hash(),
         }
-        for k in ("device_only", "pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "shard"):
+        for k in ("device_only", "pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "config4_2e26", "shard"):
             if result.get(k) is not None:
                 out[k] = result[k]
         if sharded_run:

@@ -86,6 +86,12 @@ int zk_ctx_sync(zk_ctx *ctx);
  * prover.rs:263).  With q > 1 the q raw indices are drawn in a row and each query's openings are
  * committed in turn; q = 1 is byte-identical to the reference format. */
 int zk_ctx_set_queries(zk_ctx *ctx, uint32_t n_queries);
+/* Opt-in reference self-checks.  The reference asserts its way through generate_proof; with on != 0 the same
+ * checkpoints run inside every later zk_prove* on the data as it sits in HBM: the interpolant passes through every
+ * trace point (prover.rs:64-66), every constraint division is exact and deg cp = n - 1 (prover.rs:148-159, :169), every
+ * FRI layer has its asserted degree (prover.rs:228-251).  The first checkpoint that fails is named in a ZK_ERR_CHECK
+ * (zk_last_error).  Off (default): only the last-layer check of prover.rs:238 runs. */
+int zk_ctx_set_checks(zk_ctx *ctx, int on);
 /* Selects the Merkle hash of every later zk_merkle_commit / zk_prove* on this context. */
 int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
 /* Division of the latency-bound end of zk_prove* between device and host.  A Merkle level is a chain of dependent
@@ -296,6 +302,8 @@ typedef struct zk_shard_stats {
     uint32_t root_board;        /* 1: subtree roots travel through shared memory (all ranks on one node) */
     uint32_t chunked_layers;    /* layers of the last proof exchanged in chunks overlapped with the hashing */
     uint32_t native_rccl;       /* 1: the built-in RCCL transport */
+    uint32_t rccl_nranks;       /* ncclCommCount of the communicator (checked against `world` at creation); 0 without RCCL */
+    uint32_t reserved;
     double sent_bytes;          /* bytes this rank sent to OTHER ranks during the last zk_shard_prove* / lde_commit */
     double all_to_all_bytes;    /* ... of which in the per-commitment all-to-alls */
     double setup_ms;
@@ -315,6 +323,15 @@ int zk_shard_prove_channel(zk_shard *s, zk_channel *ch);
 int zk_shard_prove(zk_shard *s, uint8_t *proof_out, size_t cap, size_t *proof_len, uint8_t state_out[32]);
 /* configs[3] shape: sharded LDE, all-to-all transpose, Merkle commit; root of f_eval (prover.rs:60-85). */
 int zk_shard_lde_commit(zk_shard *s, uint8_t root_out[32]);
+/* Merkle hash (zk_hash_kind) and number of decommitment queries, as zk_ctx_set_hash / zk_ctx_set_queries; every rank
+ * must use the same values.  Verify with zk_verify_queries(..., hash_kind, n_queries). */
+int zk_shard_set_hash(zk_shard *s, int hash_kind);
+int zk_shard_set_queries(zk_shard *s, uint32_t n_queries);
+/* Failure handling.  A rank that leaves zk_shard_prove* / zk_shard_lde_commit with an error posts an abort on the shared
+ * root board (peers waiting for it return ZK_ERR_HIP naming this rank instead of waiting out ZK_SHARD_TIMEOUT_S, default
+ * 120 s), refuses further proofs, and zk_shard_destroy then aborts its RCCL communicator (ncclCommAbort).
+ * zk_shard_inject_failure makes a rank fail that way on purpose (tests). */
+int zk_shard_inject_failure(zk_shard *s, int code);
 int zk_shard_last_transcript(const zk_shard *s, zk_transcript_info *out);
 /* This rank's shard of a layer (0 = f_eval, 1 + r = FRI layer r < sharded_layers): element j is global index
  * rank + world * j. */

@@ -27,7 +27,7 @@ static int run(int G, int rounds) {
                 uint32_t mine[8];
                 for (int i = 0; i < 8; ++i) mine[i] = (uint32_t)s * 2654435761u + (uint32_t)(r * 8 + i);
                 if ((s + r) % 37 == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));   // a slow rank
-                if (!boards[r].exchange((uint32_t)s, mine, all.data(), 30.0)) { bad[r] = 1; return; }
+                if (boards[r].exchange((uint64_t)s, mine, all.data(), 30.0) != RootBoard::kOk) { bad[r] = 1; return; }
                 for (int q = 0; q < G; ++q)
                     for (int i = 0; i < 8; ++i)
                         if (all[(size_t)q * 8 + i] != (uint32_t)s * 2654435761u + (uint32_t)(q * 8 + i)) { bad[r] = 2; return; }
@@ -56,8 +56,30 @@ int main() {
     if (!lone.open_or_create(name, 0, 2, true)) return 1;
     shm_unlink(name);
     uint32_t mine[8] = {0}, all[16];
-    if (lone.exchange(1, mine, all, 0.2)) { fprintf(stderr, "exchange with a dead rank returned\n"); return 1; }
+    if (lone.exchange(1, mine, all, 0.2) != RootBoard::kTimeout || lone.bad_peer != 1) { fprintf(stderr, "exchange with a dead rank: wrong status\n"); return 1; }
     lone.close();
+    // abort: a rank that leaves with an error releases the waiting rank at once, with its rank and code
+    {
+        RootBoard a, b;
+        snprintf(name, sizeof name, "/zkstark_amd_boardcheck_%d_a", (int)getpid());
+        if (!a.open_or_create(name, 0, 2, true) || !b.open_or_create(name, 1, 2, false)) return 1;
+        shm_unlink(name);
+        std::thread quitter([&] { std::this_thread::sleep_for(std::chrono::milliseconds(20)); b.post_abort(7); });
+        auto t0 = std::chrono::steady_clock::now();
+        RootBoard::Status st = a.exchange(1, mine, all, 30.0);
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        quitter.join();
+        if (st != RootBoard::kPeerAborted || a.bad_peer != 1 || a.bad_code != 7 || dt > 5.0) { fprintf(stderr, "abort not seen (%d, peer %d, code %u, %.2f s)\n", (int)st, a.bad_peer, a.bad_code, dt); return 1; }
+        // sequence numbers beyond 32 bits work (no wrap into the zero-filled state)
+        uint32_t m2[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+        RootBoard c;
+        snprintf(name, sizeof name, "/zkstark_amd_boardcheck_%d_w", (int)getpid());
+        if (!c.open_or_create(name, 0, 1, true)) return 1;
+        shm_unlink(name);
+        for (uint64_t sq : {0xFFFFFFFFull, 0x100000000ull, 0x100000001ull})
+            if (c.exchange(sq, m2, all, 1.0) != RootBoard::kOk || all[7] != 8) { fprintf(stderr, "wide sequence failed\n"); return 1; }
+        a.close(); b.close(); c.close();
+    }
     printf("board ok\n");
     return 0;
 }

@@ -5,10 +5,12 @@
  * zk_shard_transport): peers publish their send pointers, a barrier, device-to-device copies, a barrier.
  *   gcc -O2 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/shard_threads_check.c \
  *       -Lzkstark_amd -lzkstark_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/zkstark_amd -Wl,-rpath,/opt/rocm/lib -o shard_threads_check
- *   ./shard_threads_check world log_n log_blowup min_layer_log min_chunk_log overlap_min_log
+ *   ./shard_threads_check world log_n log_blowup min_layer_log min_chunk_log overlap_min_log [timed_reps [fail_rank]]
  */
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,7 +21,19 @@
 
 #define MAXW 16
 static int g_world;
-static pthread_barrier_t g_bar;
+/* A barrier the ranks can be released from: a rank that fails sets g_abort and never arrives, the others leave the
+ * barrier with an error instead of waiting for it for ever (the transport then reports the failure to the library). */
+static atomic_int g_abort, g_count, g_gen;
+static int g_fail_rank = -1;                  /* argv[8]: this rank injects a failure instead of proving */
+static int bar_wait(void) {
+    const int gen = atomic_load(&g_gen);
+    if (atomic_fetch_add(&g_count, 1) + 1 == g_world) { atomic_store(&g_count, 0); atomic_fetch_add(&g_gen, 1); return 0; }
+    while (atomic_load(&g_gen) == gen) {
+        if (atomic_load(&g_abort)) return 1;
+        sched_yield();
+    }
+    return 0;
+}
 static const uint32_t *const *g_send[MAXW];   /* rank r's send pointer table for the exchange in progress */
 static const uint32_t *g_gather[MAXW];
 
@@ -29,24 +43,24 @@ static int tp_all_to_all(void *user, const uint32_t *const *send, uint32_t *cons
     const int me = ((tp_user *)user)->rank;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;   /* my send pieces are complete */
     g_send[me] = send;
-    pthread_barrier_wait(&g_bar);
+    if (bar_wait()) return 2;
     int bad = 0;
     for (int q = 0; q < g_world; ++q)   /* piece `me` of rank q's table comes to my recv[q] */
         if (hipMemcpyAsync(recv[q], g_send[q][me], words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) bad = 1;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) bad = 1;
-    pthread_barrier_wait(&g_bar);       /* nobody reuses a send buffer before every peer has read it */
+    if (bar_wait()) return 2;           /* nobody reuses a send buffer before every peer has read it */
     return bad;
 }
 static int tp_all_gather(void *user, const uint32_t *send, uint32_t *recv, size_t words, void *stream) {
     const int me = ((tp_user *)user)->rank;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
     g_gather[me] = send;
-    pthread_barrier_wait(&g_bar);
+    if (bar_wait()) return 2;
     int bad = 0;
     for (int q = 0; q < g_world; ++q)
         if (hipMemcpyAsync(recv + (size_t)q * words, g_gather[q], words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) bad = 1;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) bad = 1;
-    pthread_barrier_wait(&g_bar);
+    if (bar_wait()) return 2;
     return bad;
 }
 
@@ -77,17 +91,18 @@ static void *run_rank(void *p) {
     zk_shard *sp = NULL;
     a->rc = zk_shard_create(0, a->rank, g_world, a->id, &tp, &a->opt, a->log_n, a->log_b, &sp);
     if (!a->rc) a->rc = zk_shard_trace_upload(sp, a->trace, ((size_t)1 << a->log_n) - 1);
+    if (!a->rc && a->rank == g_fail_rank) a->rc = zk_shard_inject_failure(sp, ZK_ERR_STATE);   /* leaves the proof; peers must not hang */
     if (!a->rc) a->rc = zk_shard_prove(sp, a->proof, a->cap, &a->len, a->state);
     if (!a->rc) a->rc = zk_shard_get_stats(sp, &a->stats);
     if (!a->rc && a->reps > 0) {
-        pthread_barrier_wait(&g_bar);
+        if (bar_wait()) a->rc = ZK_ERR_STATE;
         const double t0 = now_ms();
         for (int i = 0; i < a->reps && !a->rc; ++i) a->rc = zk_shard_prove(sp, a->proof, a->cap, &a->len, a->state);
-        pthread_barrier_wait(&g_bar);
+        if (!a->rc && bar_wait()) a->rc = ZK_ERR_STATE;
         a->ms_per_proof = (now_ms() - t0) / a->reps;
     }
     if (!a->rc) a->rc = zk_shard_lde_commit(sp, a->root);
-    if (a->rc) snprintf(a->err, sizeof a->err, "%s", zk_last_error());
+    if (a->rc) { snprintf(a->err, sizeof a->err, "%s", zk_last_error()); atomic_store(&g_abort, 1); }   /* release the peers */
     zk_shard_destroy(sp);
     return NULL;
 }
@@ -97,7 +112,7 @@ int main(int argc, char **argv) {
     g_world = atoi(argv[1]);
     const uint32_t log_n = (uint32_t)atoi(argv[2]), log_b = (uint32_t)atoi(argv[3]);
     if (g_world < 1 || g_world > MAXW) return 2;
-    pthread_barrier_init(&g_bar, NULL, (unsigned)g_world);
+    if (argc > 8) g_fail_rank = atoi(argv[8]);
     const size_t n = (size_t)1 << log_n, cap = zk_proof_data_len(log_n, log_b);
     uint32_t *trace = malloc((n - 1) * sizeof *trace);
     if (zk_trace_fibsq(1, 3141592, n - 1, trace)) return 1;
@@ -115,6 +130,13 @@ int main(int argc, char **argv) {
         pthread_create(&th[r], NULL, run_rank, &args[r]);
     }
     for (int r = 0; r < g_world; ++r) pthread_join(th[r], NULL);
+    if (g_fail_rank >= 0) {
+        /* the injected failure must end EVERY rank with an error (nobody hangs, nobody produces a proof) */
+        int all = 1;
+        for (int r = 0; r < g_world; ++r) { fprintf(stderr, "rank %d: %d: %s\n", r, args[r].rc, args[r].err); all = all && args[r].rc != 0; }
+        printf(all ? "failure contained: every rank returned an error\n" : "failure NOT contained\n");
+        return all ? 3 : 1;
+    }
     for (int r = 0; r < g_world; ++r)
         if (args[r].rc) { fprintf(stderr, "rank %d: %d: %s\n", r, args[r].rc, args[r].err); return 1; }
     /* the single-GPU prover on the same trace: every rank's proof must be byte-identical to it */

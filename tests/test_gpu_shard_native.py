@@ -55,6 +55,46 @@ def test_shard_world1_rccl_matches_oracle(zk, orc, log_n, log_b, opts):
     proof.verify(strict=True)
 
 
+@pytest.mark.parametrize("hash_name,queries", [("field", 1), ("sha256", 3), ("field", 4)])
+def test_shard_world1_rccl_hash_and_queries(zk, orc, hash_name, queries):
+    """zk_shard_set_hash / zk_shard_set_queries (the sharded prover was SHA-256 and single-query only): proof bytes ==
+    the oracle's with the same settings, the verifier with those settings accepts."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log_n, log_b = 13, 3
+    orc.set_hash(orc.HASH_FIELD if hash_name == "field" else orc.HASH_SHA256)
+    orc.set_queries(queries)
+    try:
+        want = orc.prove(log_n, log_b, want_vectors=False)
+    finally:
+        orc.set_hash(orc.HASH_SHA256)
+        orc.set_queries(1)
+    with zk.ShardContext(log_n, log_b, 0, 1, zk.shard_unique_id(), force_collectives=True, min_layer_log=1, min_chunk_log=6,
+                         overlap_min_log=10, hash=hash_name, queries=queries) as sp:
+        sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        proof = sp.prove()
+        st = sp.stats()
+    assert proof.data == want.proof and proof.state == want.state
+    assert st["native_rccl"] == 1 and st["rccl_nranks"] == 1
+    proof.verify(strict=(hash_name == "sha256" and queries == 1))
+
+
+def test_shard_failed_rank_refuses_and_aborts_its_communicator(zk):
+    """A rank that has left a proof with an error refuses further proofs and tears its RCCL communicator down with
+    ncclCommAbort (zk_shard_destroy), not ncclCommDestroy."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sp = zk.ShardContext(12, 3, 0, 1, zk.shard_unique_id(), force_collectives=True, min_layer_log=1, min_chunk_log=5)
+    sp.trace_upload(zk.trace_fibsq((1 << 12) - 1))
+    good = sp.prove()
+    assert sp.inject_failure(-4) == -4
+    with pytest.raises(zk.ZkError) as e:
+        sp.prove()
+    assert e.value.code == -4 and "earlier proof" in str(e.value)
+    sp.close()                                            # ncclCommAbort path
+    with zk.ShardContext(12, 3, 0, 1, zk.shard_unique_id(), force_collectives=True, min_layer_log=1, min_chunk_log=5) as sp2:
+        sp2.trace_upload(zk.trace_fibsq((1 << 12) - 1))   # a fresh communicator works after the abort
+        assert sp2.prove().data == good.data
+
+
 def test_shard_world1_local_no_collectives(zk, orc):
     """world = 1 without forcing: no transport call at all (RCCL is not even loaded for it)."""
     from zkstark_amd import _lib
@@ -123,6 +163,31 @@ def _run(world, log_n, log_b, opts, mode, timeout=900):
         p.join(timeout=120)
         assert p.exitcode == 0
     return out
+
+
+def test_shard_two_ranks_fieldhash_three_queries(orc):
+    """Two ranks on one GPU with hash = field and three queries (zk_shard_set_hash / _set_queries) against the oracle."""
+    log_n, log_b, world = 12, 3, 2
+    orc.set_hash(orc.HASH_FIELD)
+    orc.set_queries(3)
+    try:
+        want = orc.prove(log_n, log_b, want_vectors=False)
+    finally:
+        orc.set_hash(orc.HASH_SHA256)
+        orc.set_queries(1)
+    out = _run(world, log_n, log_b, dict(min_layer_log=1, min_chunk_log=6, hash="field", queries=3), "prove")
+    for rank, data, state, roots, st in out:
+        assert data == want.proof and state == want.state, f"rank {rank}"
+
+
+def test_shard_failure_of_one_rank_is_contained(threads_check):
+    """Four ranks (threads of one process); rank 2 leaves the proof with an error (zk_shard_inject_failure).  Every other
+    rank must come back with an error within seconds -- not hang in a collective, a board exchange or a barrier."""
+    import subprocess
+    out = subprocess.run([threads_check, "4", "14", "3", "1", "5", "99", "0", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert "failure contained: every rank returned an error" in out.stdout
+    assert "injected failure on rank 2" in out.stderr
 
 
 @pytest.mark.parametrize("world,log_n,log_b,opts", [

@@ -86,9 +86,21 @@ def notes(elf_path):
     return [k for k in kernels if "name" in k]
 
 
+_DISASM = {}
+
+
+def _disasm(elf_path):
+    """llvm-objdump -d of one code object (cached per content: several queries walk the same text)."""
+    with open(elf_path, "rb") as f:
+        key = hash(f.read())
+    if key not in _DISASM:
+        _DISASM[key] = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf_path], capture_output=True, text=True).stdout
+    return _DISASM[key]
+
+
 def isa_counts(elf_path):
     """{mangled name: {valu, salu, lds, vmem, total}} from the disassembly."""
-    txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf_path], capture_output=True, text=True).stdout
+    txt = _disasm(elf_path)
     res, cur = {}, None
     for line in txt.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -117,7 +129,7 @@ def isa_counts(elf_path):
 def loops(elf_path, mangled):
     """[(start offset, end offset, VALU instructions)] of every backward branch (loop) in one kernel; offsets are
     relative to the kernel's first instruction.  An innermost loop's count is what one trip executes."""
-    txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf_path], capture_output=True, text=True).stdout
+    txt = _disasm(elf_path)
     inside, rows, base = False, [], None
     for line in txt.splitlines():
         m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)

@@ -1,5 +1,6 @@
 // montmul_probe.hip -- which instruction sequence should mont_mul (field.hpp) compile to on gfx950?
 //   v0: the 64-bit product form (hipcc emits v_mad_u64_u32 + v_lshl_add + v_mul_hi + a 64-bit compare: 8 VALU)
+//   v2: v_mad_u64_u32 + v_lshl_add + v_mul_hi + v_sub_co + v_add + v_cndmask (6 VALU: what field.hpp now compiles to)
 //   v1: v_mul_lo + v_mul_hi + v_lshl_add + v_mul_hi + v_sub_co + v_add + v_cndmask (7 VALU, borrow from the subtract)
 // and the issue rate of the single ops involved (v_mad_u64_u32, v_cmp_lt_u64, v_sub_co_u32, v_cndmask_b32).
 // Four independent chains per lane so that dependent-issue latency does not hide the instruction cost; 10 launches
@@ -30,6 +31,16 @@ __device__ __forceinline__ uint32_t mm1(uint32_t a, uint32_t b) {
     return borrow ? r + P : r;
 }
 
+__device__ __forceinline__ uint32_t mm2(uint32_t a, uint32_t b) {   // field.hpp as of round 3: mad_u64 + borrow from the subtract
+    uint64_t t = (uint64_t)a * b;
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo + (lo << 30);
+    uint32_t mp_hi = __umulhi(m, P);
+    uint32_t r;
+    bool borrow = __builtin_sub_overflow(hi, mp_hi, &r);
+    return borrow ? r + P : r;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void chain(uint32_t* out, uint32_t seed) {
     uint32_t a = (seed + threadIdx.x) % P, b = (seed * 3 + threadIdx.x + 1) % P, c = (seed * 5 + 7 + blockIdx.x) % P, d = (seed * 7 + 11) % P;
@@ -39,7 +50,8 @@ __global__ __launch_bounds__(256) void chain(uint32_t* out, uint32_t seed) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (V == 0) { a = mm0(a, b); b = mm0(b, c); c = mm0(c, d); d = mm0(d, w ^ (uint32_t)u); }
-            else        { a = mm1(a, b); b = mm1(b, c); c = mm1(c, d); d = mm1(d, w ^ (uint32_t)u); }
+            else if (V == 1) { a = mm1(a, b); b = mm1(b, c); c = mm1(c, d); d = mm1(d, w ^ (uint32_t)u); }
+            else             { a = mm2(a, b); b = mm2(b, c); c = mm2(c, d); d = mm2(d, w ^ (uint32_t)u); }
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a ^ b ^ c ^ d;
@@ -122,15 +134,19 @@ int main() {
     CHK(hipMemcpy(r0.data(), d_out, n * 4, hipMemcpyDeviceToHost));
     hipLaunchKernelGGL(chain<1>, dim3(cus * 8), dim3(256), 0, 0, d_out, 99u);
     CHK(hipMemcpy(r1.data(), d_out, n * 4, hipMemcpyDeviceToHost));
-    printf("variants agree: %s\n", r0 == r1 ? "yes" : "NO");
+    std::vector<uint32_t> r2(n);
+    hipLaunchKernelGGL(chain<2>, dim3(cus * 8), dim3(256), 0, 0, d_out, 99u);
+    CHK(hipMemcpy(r2.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+    printf("variants agree: %s\n", (r0 == r1 && r0 == r2) ? "yes" : "NO");
     const double mm = (double)ITER * UNROLL * 4;
     timeit("mont_mul v0 (mad_u64)", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(chain<0>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("mont_mul v1 (mul_lo/hi)", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(chain<1>, dim3(b), dim3(256), 0, 0, d_out, s); });
+    timeit("mont_mul v2 (mad_u64+sub_co)", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(chain<2>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("v_mad_u64_u32", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(op_rate<0>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("v_mul_hi_u32", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(op_rate<1>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("v_mul_lo_u32", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(op_rate<5>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("v_cmp_lt_u64", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(op_rate<2>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("v_sub_co_u32", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(op_rate<3>, dim3(b), dim3(256), 0, 0, d_out, s); });
     timeit("v_cndmask_b32", mm, cus, [&](int b, uint32_t s) { hipLaunchKernelGGL(op_rate<4>, dim3(b), dim3(256), 0, 0, d_out, s); });
-    return r0 == r1 ? 0 : 2;
+    return (r0 == r1 && r0 == r2) ? 0 : 2;
 }

@@ -47,7 +47,7 @@ class ShardOptions(C.Structure):
 
 class ShardStats(C.Structure):
     _fields_ = [("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
-                ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double)]
+                ("rccl_nranks", C.c_uint32), ("reserved", C.c_uint32), ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double)]
 
 
 class ChainProbe(C.Structure):
@@ -83,6 +83,7 @@ SYMBOLS = {
     "zk_ctx_device_bytes": (_sz, [_vp]),
     "zk_ctx_sync": (_int, [_vp]),
     "zk_ctx_set_hash": (_int, [_vp, _int]),
+    "zk_ctx_set_checks": (_int, [_vp, _int]),
     "zk_ctx_set_host_levels": (_int, [_vp, _u32, _u32]),
     "zk_ctx_get_host_levels": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "zk_ctx_set_queries": (_int, [_vp, _u32]),
@@ -160,6 +161,9 @@ SYMBOLS = {
     "zk_shard_prove_channel": (_int, [_vp, _vp]),
     "zk_shard_prove": (_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "zk_shard_lde_commit": (_int, [_vp, _vp]),
+    "zk_shard_set_hash": (_int, [_vp, _int]),
+    "zk_shard_set_queries": (_int, [_vp, _u32]),
+    "zk_shard_inject_failure": (_int, [_vp, _int]),
     "zk_shard_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
     "zk_shard_layer_read": (_int, [_vp, _u32, _sz, _sz, _vp]),
     "zk_shard_get_stats": (_int, [_vp, C.POINTER(ShardStats)]),

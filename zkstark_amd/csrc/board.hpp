@@ -4,13 +4,18 @@
 // A commitment of the sharded prover ends with every rank needing all G roots on the host, to hash the top of the
 // tree and feed the channel (prover.rs:85).  As a device collective that is an all-gather plus a device-to-host
 // read, ~100 us of fixed cost for 256 bytes; through a shared page it is one store and G polled loads.
+//
+// The page also carries one ABORT word per rank: a rank that leaves a proof with an error posts its code there, and
+// every rank waiting in an exchange sees it within microseconds instead of waiting out the timeout.
 #pragma once
 #include <fcntl.h>
+#include <sched.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -20,13 +25,20 @@ namespace impl {
 
 struct RootBoard {
     static constexpr int kRing = 4;        // a rank cannot run more than one exchange ahead of the slowest one
-    uint32_t* slots = nullptr;             // [kRing][G][16]: 8 digest words, word 8 = sequence number
+    static constexpr int kSlotWords = 16;  // 8 digest words, words 8-9 = the 64-bit sequence number (8-byte aligned)
+    enum Status { kOk = 0, kTimeout = 1, kPeerAborted = 2 };
+    uint32_t* slots = nullptr;             // [kRing][G][kSlotWords], then [G] abort words
     size_t bytes = 0;
     int G = 0, rank = 0;
+    // filled by a failed exchange: the rank that was waited for (or that aborted), and its abort code
+    int bad_peer = -1;
+    uint32_t bad_code = 0;
+
+    uint32_t* abort_words() const { return slots + (size_t)kRing * G * kSlotWords; }
 
     bool open_or_create(const char* name, int rank_, int world, bool create) {
         G = world; rank = rank_;
-        bytes = (size_t)kRing * world * 16 * sizeof(uint32_t);
+        bytes = ((size_t)kRing * world * kSlotWords + (size_t)((world + 15) & ~15)) * sizeof(uint32_t);
         int fd;
         if (create) {
             shm_unlink(name);                                       // a stale object of a crashed run
@@ -49,26 +61,52 @@ struct RootBoard {
         if (slots) munmap(slots, bytes);
         slots = nullptr;
     }
-    // Exchange number seq = 1, 2, ... (the same on every rank).  mine: this rank's root as 8 state words;
-    // all: [G][8] out.  Returns false on timeout (a rank died or diverged).
-    bool exchange(uint32_t seq, const uint32_t mine[8], uint32_t* all, double timeout_s = 120.0) {
-        uint32_t* row = slots + (size_t)(seq % kRing) * G * 16;
-        uint32_t* my = row + (size_t)rank * 16;
+    // This rank is leaving the protocol with an error: every peer's pending and future exchange fails at once.
+    void post_abort(uint32_t code) {
+        if (slots) __atomic_store_n(abort_words() + rank, code ? code : 1u, __ATOMIC_RELEASE);
+    }
+    // -1, or the lowest rank that has posted an abort (its code in bad_code)
+    int aborted_peer() {
+        if (!slots) return -1;
+        for (int q = 0; q < G; ++q) {
+            const uint32_t c = __atomic_load_n(abort_words() + q, __ATOMIC_ACQUIRE);
+            if (c) { bad_code = c; return q; }
+        }
+        return -1;
+    }
+    // Exchange number seq = 1, 2, ... (the same on every rank; 64 bits: it never wraps into the zero-filled state).
+    // mine: this rank's root as 8 state words; all: [G][8] out.  kTimeout: rank bad_peer never posted exchange seq
+    // (it died or diverged); kPeerAborted: rank bad_peer left with error bad_code.
+    Status exchange(uint64_t seq, const uint32_t mine[8], uint32_t* all, double timeout_s = 120.0) {
+        uint32_t* row = slots + (size_t)(seq % kRing) * G * kSlotWords;
+        uint32_t* my = row + (size_t)rank * kSlotWords;
         for (int i = 0; i < 8; ++i) __atomic_store_n(my + i, mine[i], __ATOMIC_RELAXED);
-        __atomic_store_n(my + 8, seq, __ATOMIC_RELEASE);            // after the digest
+        __atomic_store_n(reinterpret_cast<uint64_t*>(my + 8), seq, __ATOMIC_RELEASE);   // after the digest
         auto t0 = std::chrono::steady_clock::now();
         for (int q = 0; q < G; ++q) {
-            const uint32_t* src = row + (size_t)q * 16;
+            const uint32_t* src = row + (size_t)q * kSlotWords;
             uint64_t spins = 0;
-            while (__atomic_load_n(src + 8, __ATOMIC_ACQUIRE) != seq) {
+            while (__atomic_load_n(reinterpret_cast<const uint64_t*>(src + 8), __ATOMIC_ACQUIRE) != seq) {
+                ++spins;
+                if (spins < 4096) {
 #if defined(__x86_64__) || defined(__i386__)
-                __builtin_ia32_pause();
+                    __builtin_ia32_pause();
 #endif
-                if ((++spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+                    continue;
+                }
+                // a peer is late by more than a few microseconds: stop burning the core it may need (ranks as threads
+                // under a CPU quota, RCCL proxy threads), look for aborts, and watch the clock
+                if ((spins & 63) == 0) {
+                    const int ab = aborted_peer();
+                    if (ab >= 0) { bad_peer = ab; return kPeerAborted; }
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { bad_peer = q; return kTimeout; }
+                }
+                if (spins < 65536) sched_yield();
+                else { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
             }
             for (int i = 0; i < 8; ++i) all[(size_t)q * 8 + i] = __atomic_load_n(src + i, __ATOMIC_RELAXED);
         }
-        return true;
+        return kOk;
     }
 };
 

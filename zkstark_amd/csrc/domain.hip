@@ -242,14 +242,19 @@ int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t lo
 
 // Waits until the mailbox carries the sequence number of the last commit launch (polling host-coherent
 // memory: no blit kernel, no stream synchronisation on the commit -> challenge path).
-int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream) {
+int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*), void* poll_user) {
     auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
 #if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
         __builtin_ia32_pause();                          // be kind to the sibling hardware thread
 #endif
-        if ((++spins & 0xFFFF) == 0) {
+        if (poll && (++spins & 0xFFF) == 0) {
+            if (int prc = poll(poll_user)) return prc;
+        } else if (!poll) {
+            ++spins;
+        }
+        if ((spins & 0xFFFF) == 0) {
             hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
                 return fail(ZK_ERR_HIP, "merkle digests were never posted (stream drained)");

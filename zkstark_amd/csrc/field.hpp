@@ -50,13 +50,23 @@ ZK_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 // Montgomery product a*b*R^-1 mod P, result canonical in [0, P).
 // Requires a*b < P*2^32, i.e. at least one operand < P (the other may be any u32,
 // which is how raw u32 challenges >= P are absorbed: field.rs:20-24).
+// Written so that hipcc emits six VALU instructions: v_mad_u64_u32 (lo and hi of a*b in one four-cycle op),
+// v_lshl_add_u32, v_mul_hi_u32, v_sub_co_u32 (the borrow IS the comparison), v_add_u32, v_cndmask_b32.  Comparing
+// `hi < mp_hi` instead costs a 64-bit compare and two moves more (tools/montmul_probe.hip).
+ZK_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
 ZK_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
     uint64_t t = (uint64_t)a * b;
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo + (lo << 30);                           // lo * P_INV mod 2^32
-    uint32_t mp_hi = (uint32_t)(((uint64_t)m * P) >> 32);   // low words of t and m*P are equal
-    uint32_t r = hi - mp_hi;
-    return hi < mp_hi ? r + P : r;
+    uint32_t mp_hi = mul_hi_u32(m, P);                      // low words of t and m*P are equal
+    uint32_t r;
+    return __builtin_sub_overflow(hi, mp_hi, &r) ? r + P : r;
 }
 
 // Host-side helpers (setup, verifier, scalar API).  Plain residues in and out.

@@ -76,12 +76,35 @@ ZK_HD void fh_external(uint32_t (&s)[kFhT]) {
 #pragma unroll
     for (int i = 0; i < kFhT; ++i) s[i] = add(s[i], col[i & 3]);
 }
+// (a * b + c) * R^-1 mod P for a 64-bit addend c with a * b + c < P * 2^32: the addend rides in v_mad_u64_u32 for free
+ZK_HD uint32_t mont_mul_add(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t t = (uint64_t)a * b + c;
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo + (lo << 30);
+    uint32_t mp_hi = mul_hi_u32(m, P);
+    uint32_t r;
+    return __builtin_sub_overflow(hi, mp_hi, &r) ? r + P : r;
+}
+// v < 2^36 (a sum of 16 residues) -> v mod P.  q' = floor((v >> 30) / 3) is floor(v / P) or one more (P = 3 * 2^30 + 1),
+// so v - q' P lies in [-P, P): one conditional correction on the 64-bit borrow.
+ZK_HD uint32_t fh_reduce36(uint64_t v) {
+    uint32_t x = (uint32_t)(v >> 30);                 // < 64
+    uint32_t q = (x * 43u) >> 7;                      // floor(x / 3) for x < 128
+    uint64_t t = (uint64_t)q * P;
+    uint64_t r = v - t;                               // as a signed 64-bit value in [-P, P)
+    uint32_t lo = (uint32_t)r;
+    return (int64_t)r < 0 ? lo + P : lo;
+}
+// I: s_i <- d_i s_i + sum_j s_j.  The sum is accumulated in 64 bits (no per-add correction) and reduced once; each
+// d_i s_i + sum is ONE Montgomery reduction of s_i * (d_i R) + (sum R), the addend riding in the multiply-add.
 ZK_HD void fh_internal(uint32_t (&s)[kFhT], const FieldHashConsts& c) {
-    uint32_t sum = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < kFhT; ++i) sum = add(sum, s[i]);
+    for (int i = 0; i < kFhT; ++i) acc += s[i];
+    const uint32_t sum = fh_reduce36(acc);
+    const uint64_t sum_r = mont_mul(sum, R2);          // sum * R mod P
 #pragma unroll
-    for (int i = 0; i < kFhT; ++i) s[i] = add(i == 1 ? s[i] : mont_mul(s[i], c.diag[i]), sum);
+    for (int i = 0; i < kFhT; ++i) s[i] = i == 1 ? add(s[i], sum) : mont_mul_add(s[i], c.diag[i], sum_r);
 }
 // s in Montgomery form
 ZK_HD void fh_permute(uint32_t (&s)[kFhT], const FieldHashConsts& c) {

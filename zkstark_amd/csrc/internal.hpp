@@ -115,8 +115,10 @@ int fold_args(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t l
 int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw, hipStream_t s,
              Profiler* prof);
 
-// Waits until *flag (host-mapped memory written by a commit launch on `stream`) equals `want`.
-int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream);
+// Waits until *flag (host-mapped memory written by a commit launch on `stream`) equals `want`.  poll (optional) is
+// called every few thousand spins; a non-zero return ends the wait with that code (the sharded prover looks for a
+// peer that has left the proof: the launch may sit behind a collective that will never complete).
+int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*) = nullptr, void* poll_user = nullptr);
 double now_us();
 // merkle.rs:54-71: node indices of the authentication path of `leaf` in a tree of m leaves
 void path_nodes(size_t m, size_t leaf, std::vector<size_t>& out);

@@ -246,6 +246,31 @@ hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_
     return hipGetLastError();
 }
 
+// Degree check of the opt-in reference self-checks (prover.rs:154-156, :169, :228-251): coef is the unscaled DIF output
+// (mixed-radix digit-reversed order) of a layer; out[0] += number of non-zero coefficients of true index >= bound,
+// out[1] = the coefficient of true index bound - 1 (the asserted degree must be reached exactly).
+__global__ void degree_check_kernel(const uint32_t* coef, uint32_t log_m, DigitArgs dg, uint32_t bound, uint32_t* out) {
+    size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= ((size_t)1 << log_m)) return;
+    uint32_t k = 0, rem = log_m, sh = 0;
+    for (uint32_t d = 0; d < dg.nd; ++d) {
+        rem -= dg.bits[d];
+        k |= (((uint32_t)pos >> rem) & ((1u << dg.bits[d]) - 1u)) << sh;
+        sh += dg.bits[d];
+    }
+    const uint32_t v = coef[pos];
+    if (k >= bound && v != 0) atomicAdd(&out[0], 1u);
+    if (k + 1 == bound) out[1] = v;
+}
+hipError_t launch_degree_check(const uint32_t* coef, uint32_t log_m, uint32_t nd, const uint32_t* dig_bits, uint32_t bound, uint32_t* out, hipStream_t s) {
+    DigitArgs dg{};
+    dg.nd = nd;
+    for (uint32_t i = 0; i < nd; ++i) dg.bits[i] = dig_bits[i];
+    size_t m = (size_t)1 << log_m;
+    hipLaunchKernelGGL(degree_check_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, s, coef, log_m, dg, bound, out);
+    return hipGetLastError();
+}
+
 // ===========================================================================
 // Composition
 // ===========================================================================
@@ -463,23 +488,24 @@ __device__ __forceinline__ Digest lds_digest(const uint4* p) {
     return d;
 }
 
-// HEAP = false: every pending LEFT sibling group waits in LDS ((k + 1) x 2 KiB per wave: 40 KiB per 256-thread
-// workgroup at k = 4, four waves per SIMD).  HEAP = true: only level 0 pairs through LDS (4 KiB per wave, eight waves
-// per SIMD whatever k is); a pending group of a higher level waits where it already is -- every digest is written to
-// the heap as it is produced -- and is read back (L2) together with its right sibling when that arrives.  A level-l
-// pairing happens once per 2^(l+1) groups, so the re-read adds 32 B per inner hash above level 0.
-template <class SRC, bool LEAF, int HASH, bool HEAP>
-__device__ __forceinline__ void merkle_subtree_body(const SRC& src, uint32_t* nodes, uint32_t depth_in, uint32_t k, size_t off) {
+template <class SRC, bool LEAF, int HASH>
+__global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src, uint32_t* nodes,
+                                                                        uint32_t depth_in, uint32_t k, size_t off) {
+    // per wave: k pending LEFT sibling groups (one per level) + one scratch group for the right sibling of the
+    // pairing in progress, 64 digests x 2 uint4 each = (k + 1) x 2 KiB: 40 KiB per workgroup at k = 4, four waves per
+    // SIMD.  (Round 3 tried keeping only level 0 in LDS and re-reading the pending groups of higher levels from the
+    // heap, where every digest is written anyway: 4 KiB per wave, <= 56 VGPRs, eight waves per SIMD and any k -- and
+    // measured 6.19 ms per 2^24 proof against 6.07 ms for this kernel, profiles/r03_ab_subtree_heap.txt: SHA-256 as
+    // compiled does not issue faster with more resident waves, and the second inlined copy of the hash costs more.)
     extern __shared__ __attribute__((aligned(16))) uint4 stage[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const size_t gwave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const size_t gwave = (size_t)blockIdx.x * (kMerkleThreads / 64) + wave;
     // first input of this wave; `off` = position of a chunk's first node at this depth (0 for a whole
     // tree): a chunk is an aligned sub-range of the leaves, built into its place in the heap
     const size_t base = (gwave << (6 + k)) + off;
     const size_t in_base = ((size_t)1 << depth_in) - 1;
-    const uint32_t groups = HEAP ? 2u : k + 1u;                  // LDS groups of 64 digests per wave
-    uint4* my = stage + (size_t)wave * groups * 128;
-    uint4* scratch = my + (size_t)(groups - 1u) * 128;
+    uint4* my = stage + (size_t)wave * (k + 1) * 128;
+    uint4* scratch = my + (size_t)k * 128;
 #pragma unroll 1
     for (uint32_t i = 0; i < (1u << k); ++i) {
         Digest d;
@@ -493,45 +519,23 @@ __device__ __forceinline__ void merkle_subtree_body(const SRC& src, uint32_t* no
         uint32_t idx = i, lvl = 0;
 #pragma unroll 1
         while (lvl < k) {                                        // wave-uniform
-            // (the two paths each carry their own inlined hash: sharing one call site costs ~20 VGPRs in the
-            // register allocation of either variant, i.e. two waves per SIMD of occupancy)
-            if (HEAP && lvl > 0) {
-                if (!(idx & 1u)) break;                          // waits in the heap (stored when it was produced)
-                // this wave's own stores of both groups have reached L2 before it reads them back
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                // children 2*lane, 2*lane+1 of the 128 consecutive nodes [left group | this group] of level lvl
-                const size_t first = (((size_t)1 << (depth_in - lvl)) - 1) + (base >> lvl) + (size_t)(idx - 1u) * 64;
-                Digest l = load_digest(nodes, first + 2 * lane), r = load_digest(nodes, first + 2 * lane + 1);
-                d = Hasher<HASH>::inner(l, r);
-            } else {
-                uint4* left = my + lvl * 128;
-                uint4* grp = (idx & 1u) ? scratch : left;
-                grp[2 * lane] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
-                grp[2 * lane + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
-                if (!(idx & 1u)) break;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // children 2*lane, 2*lane+1 of the 128 buffered nodes: lanes 0-31 pair the left group, lanes 32-63 the right
-                const uint4* x = (lane < 32u ? left : scratch - 128) + 4 * lane;
-                Digest l = lds_digest(x), r = lds_digest(x + 2);
-                __builtin_amdgcn_wave_barrier();
-                d = Hasher<HASH>::inner(l, r);
-            }
+            uint4* left = my + lvl * 128;
+            uint4* grp = (idx & 1u) ? scratch : left;
+            grp[2 * lane] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+            grp[2 * lane + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+            if (!(idx & 1u)) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // children 2*lane, 2*lane+1 of the 128 buffered nodes: lanes 0-31 pair the left group, lanes 32-63 the right
+            const uint4* x = (lane < 32u ? left : scratch - 128) + 4 * lane;
+            Digest l = lds_digest(x), r = lds_digest(x + 2);
+            __builtin_amdgcn_wave_barrier();
+            d = Hasher<HASH>::inner(l, r);
             idx >>= 1;
             ++lvl;
             store_digest(nodes, (((size_t)1 << (depth_in - lvl)) - 1) + (base >> lvl) + (size_t)idx * 64 + lane, d);
         }
     }
-}
-
-// One entry point per hash, so that the SHA-256 and the field-hash variants can carry different launch bounds.
-template <class SRC, bool LEAF, bool HEAP>
-__global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t k, size_t off) {
-    merkle_subtree_body<SRC, LEAF, 0, HEAP>(src, nodes, depth_in, k, off);
-}
-template <class SRC, bool LEAF, bool HEAP>
-__global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_fh_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t k, size_t off) {
-    merkle_subtree_body<SRC, LEAF, 1, HEAP>(src, nodes, depth_in, k, off);
 }
 
 // Latency-bound part of a tree.  A level with <= 65 536 nodes costs one hash latency however it
@@ -716,15 +720,8 @@ static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t h
     const uint32_t x = (uint32_t)atoi(e);
     return (x < lo || x > hi) ? dflt : x;
 }
-// Tuning switches (environment, read once).  ZK_MERKLE_HEAP: 1 = pending groups above level 0 wait in the heap
-// (8 waves per SIMD), 0 = in LDS (4 waves per SIMD at k = 4).  ZK_MERKLE_MAX_K: levels per subtree launch.
-// ZK_MERKLE_WG_WAVES: waves per workgroup of the subtree kernels (1, 2 or 4: the dispatch granularity).
-static bool merkle_heap() { static const bool v = env_u32("ZK_MERKLE_HEAP", 1, 0, 1) != 0; return v; }
-static uint32_t merkle_max_k() {
-    static const uint32_t v = env_u32("ZK_MERKLE_MAX_K", kMerkleMaxK, 1, merkle_heap() ? 8 : kMerkleMaxK);
-    return v;
-}
-static uint32_t merkle_wg_waves() { static const uint32_t v = env_u32("ZK_MERKLE_WG_WAVES", 4, 1, 4); return v == 3 ? 4 : v; }
+// Tuning switches (environment, read once).  ZK_MERKLE_MAX_K: levels per subtree launch.
+static uint32_t merkle_max_k() { static const uint32_t v = env_u32("ZK_MERKLE_MAX_K", kMerkleMaxK, 1, kMerkleMaxK); return v; }
 static uint32_t merkle_latency_log() { static const uint32_t v = env_u32("ZK_MERKLE_LATENCY_LOG", kMerkleLatencyLogDefault, 12, 24); return v; }
 
 // Builds the levels of a heap over 2^log_m leaves that lie above the aligned leaf range
@@ -755,20 +752,16 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
         uint32_t k = depth - floor_depth;
         if (k > merkle_max_k()) k = merkle_max_k();
         size_t lanes = (size_t)1 << (depth - stop - k);         // >= 2^17: a multiple of the block size
-        const bool heap = merkle_heap();
-        const uint32_t threads = 64 * merkle_wg_waves();
-        uint32_t blocks = (uint32_t)(lanes / threads);
-        size_t sh = (size_t)(threads / 64) * (heap ? 2 : k + 1) * 128 * sizeof(uint4);
+        uint32_t blocks = (uint32_t)(lanes / kMerkleThreads);
+        size_t sh = (size_t)(kMerkleThreads / 64) * (k + 1) * 128 * sizeof(uint4);
         ScopedKernelTimer tm(prof, leaf ? K_MERKLE_LEAF : K_MERKLE_INNER, first_bytes(merkle_bytes(leaf, depth - stop, k)), s, merkle_ops(leaf, depth - stop, k, hash));
-#define ZK_SUBTREE(KERN, S, LF, HP, arg) hipLaunchKernelGGL((KERN<S, LF, HP>), dim3(blocks), dim3(threads), sh, s, arg, nodes, depth, k, off_at(depth))
         if (hash) {
-            if (leaf) { if (heap) ZK_SUBTREE(merkle_subtree_fh_kernel, SRC, true, true, src); else ZK_SUBTREE(merkle_subtree_fh_kernel, SRC, true, false, src); }
-            else { if (heap) ZK_SUBTREE(merkle_subtree_fh_kernel, PlainSrc, false, true, none); else ZK_SUBTREE(merkle_subtree_fh_kernel, PlainSrc, false, false, none); }
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k, off_at(depth));
+            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k, off_at(depth));
         } else {
-            if (leaf) { if (heap) ZK_SUBTREE(merkle_subtree_kernel, SRC, true, true, src); else ZK_SUBTREE(merkle_subtree_kernel, SRC, true, false, src); }
-            else { if (heap) ZK_SUBTREE(merkle_subtree_kernel, PlainSrc, false, true, none); else ZK_SUBTREE(merkle_subtree_kernel, PlainSrc, false, false, none); }
+            if (leaf) hipLaunchKernelGGL((merkle_subtree_kernel<SRC, true, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, src, nodes, depth, k, off_at(depth));
+            else hipLaunchKernelGGL((merkle_subtree_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kMerkleThreads), sh, s, none, nodes, depth, k, off_at(depth));
         }
-#undef ZK_SUBTREE
         leaf = false;
         depth -= k;
     }

@@ -28,8 +28,8 @@ constexpr double kShaInnerOps = 2293.0;
 constexpr double kNttOpsPerElement = 78.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU: 2456-2560 per wave of 32 elements/lane)
 // field-native hash: one permutation per hash.  Dynamic ISA count (tools/kernel_descriptors.py --loops: 4 + 4 trips of the
 // full-round loops, 22 of the partial-round loop, plus the straight-line rest), confirmed by SQ_INSTS_VALU (profiles/)
-constexpr double kFieldLeafOps = 12550.0;
-constexpr double kFieldInnerOps = 12567.0;
+constexpr double kFieldLeafOps = 9080.0;
+constexpr double kFieldInnerOps = 9092.0;
 
 struct Profiler {
     uint32_t mask = 0;
@@ -121,6 +121,9 @@ hipError_t launch_ntt_pass(const NttPassArgs& a, NttMode mode, hipStream_t s, Pr
 // out[pos] = in[true_index(pos)] for the mixed-radix digit reversal (standalone NTT API only)
 hipError_t launch_digit_reverse(const uint32_t* in, uint32_t* out, uint32_t log_m, uint32_t nd,
                                 const uint32_t* dig_bits, int to_natural, hipStream_t s);
+
+// self-checks: coef = unscaled DIF output of a layer; out[0] += non-zero coefficients of true index >= bound, out[1] = coefficient bound - 1
+hipError_t launch_degree_check(const uint32_t* coef, uint32_t log_m, uint32_t nd, const uint32_t* dig_bits, uint32_t bound, uint32_t* out, hipStream_t s);
 
 // inv_xm1[i] = 1 / (shift h^i - 1) in Montgomery form, i < N (domain setup)
 hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s);

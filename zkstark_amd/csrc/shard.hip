@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -28,6 +29,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 
 #include "host_sha.hpp"
 #include "sha256.hpp"
@@ -46,6 +48,9 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -77,6 +82,9 @@ const RcclApi* rccl_api() {
     api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+    api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.Send = (decltype(api.Send))sym("ncclSend");
@@ -123,7 +131,12 @@ struct zk_shard {
     // root board
     RootBoard board;
     bool use_board = false;
-    uint32_t board_seq = 0;
+    uint64_t board_seq = 0;
+    // settings (zk_shard_set_hash / _set_queries) and failure state
+    int hash = ZK_HASH_SHA256;
+    uint32_t queries = 1;
+    double timeout_s = 120.0;                          // host-side waits on peers (ZK_SHARD_TIMEOUT_S)
+    bool failed = false;                               // this rank left a collective phase with an error
     // per proof
     std::vector<std::vector<uint32_t>> tops;           // per tree: heap of 2G-1 digests (8 words each), root first
     bool have_trace = false;
@@ -140,6 +153,42 @@ uint32_t* layer_ptr(zk_shard* s, uint32_t lid) { return s->d_layers + s->layer_o
 uint32_t* tree_ptr(zk_shard* s, uint32_t t) { return s->d_trees + s->tree_off[t]; }
 bool collectives(const zk_shard* s) { return s->G > 1 || s->force; }
 
+// Host-side wait for stream work that depends on the peers (a collective).  Bounded (timeout_s), and ended at once by
+// a peer that has posted an abort on the root board; the message names the phase, this rank and the peer.
+int sync_peers(zk_shard* s, hipStream_t st, const char* what) {
+    if (!collectives(s)) { HIPCHK(hipStreamSynchronize(st)); return ZK_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return ZK_OK;
+        if (q != hipErrorNotReady) return fail(ZK_ERR_HIP, "rank %d of %d: device error while waiting for %s: %s", s->rank, s->G, what, hipGetErrorString(q));
+        if ((++spins & 127) == 0) {
+            if (s->use_board) {
+                const int ab = s->board.aborted_peer();
+                if (ab >= 0 && ab != s->rank)
+                    return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d while this rank waited for %s", s->rank, s->G, ab,
+                                -(int)s->board.bad_code, what);
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > s->timeout_s)
+                return fail(ZK_ERR_HIP, "rank %d of %d: timed out after %.0f s waiting for %s (a peer never arrived; exchange #%llu)", s->rank, s->G, dt,
+                            what, (unsigned long long)s->board_seq);
+        }
+        if (spins > 4096) sched_yield();
+    }
+}
+
+// This rank leaves a collective phase with an error: tell the peers (root board) so that they stop waiting for it,
+// remember it for zk_shard_destroy (ncclCommAbort instead of ncclCommDestroy), and say so on stderr.
+int rank_failed(zk_shard* s, int rc) {
+    if (!rc || s->failed) return rc;
+    s->failed = true;
+    if (s->use_board) s->board.post_abort((uint32_t)(-rc));
+    if (collectives(s)) fprintf(stderr, "[zk_shard] rank %d of %d failed (%d): %s\n", s->rank, s->G, rc, last_error());
+    return rc;
+}
+
 // ---- built-in transport: RCCL ---------------------------------------------------------------
 #define NCCLCHK(s, expr)                                                                                  \
     do {                                                                                                  \
@@ -151,13 +200,21 @@ bool collectives(const zk_shard* s) { return s->G > 1 || s->force; }
 int rccl_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* recv, size_t words, void* stream) {
     zk_shard* s = static_cast<zk_shard*>(user);
     hipStream_t st = (hipStream_t)stream;
-    // the all-to-all of the four-step transpose: every pair exchanges one piece, all 7 xGMI links busy at once
+    // the all-to-all of the four-step transpose: every pair exchanges one piece, all 7 xGMI links busy at once.
+    // A failed Send / Recv must not leave the thread's group open (every later RCCL call would be undefined):
+    // the group is always ended, then the first error is reported.
     NCCLCHK(s, s->rccl->GroupStart());
-    for (int p = 0; p < s->G; ++p) {
-        NCCLCHK(s, s->rccl->Send(send[p], words, ncclUint32, p, s->comm, st));
-        NCCLCHK(s, s->rccl->Recv(recv[p], words, ncclUint32, p, s->comm, st));
+    ncclResult_t first = ncclSuccess;
+    int bad_peer = -1;
+    for (int p = 0; p < s->G && first == ncclSuccess; ++p) {
+        ncclResult_t r = s->rccl->Send(send[p], words, ncclUint32, p, s->comm, st);
+        if (r == ncclSuccess) r = s->rccl->Recv(recv[p], words, ncclUint32, p, s->comm, st);
+        if (r != ncclSuccess) { first = r; bad_peer = p; }
     }
-    NCCLCHK(s, s->rccl->GroupEnd());
+    const ncclResult_t end = s->rccl->GroupEnd();
+    if (first != ncclSuccess)
+        return fail(ZK_ERR_HIP, "rank %d: ncclSend/ncclRecv with peer %d failed: %s", s->rank, bad_peer, s->rccl->GetErrorString(first));
+    if (end != ncclSuccess) return fail(ZK_ERR_HIP, "rank %d: ncclGroupEnd failed: %s", s->rank, s->rccl->GetErrorString(end));
     return ZK_OK;
 }
 int rccl_all_gather(void* user, const uint32_t* send, uint32_t* recv, size_t words, void* stream) {
@@ -189,17 +246,47 @@ int agree(zk_shard* s, bool ok, bool* all_ok) {
     int rc = all_gather(s, s->d_small, s->d_small + 8, 1, s->stream);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->h_small + 8, s->d_small + 8, 4 * (size_t)s->G, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    if ((rc = sync_peers(s, s->stream, "the setup agreement (all-gather of one word)"))) return rc;
     *all_ok = true;
     for (int q = 0; q < s->G; ++q) *all_ok = *all_ok && s->h_small[8 + q] == 1u;
     return ZK_OK;
 }
 
 // merkle.rs:38-47 over the G subtree roots (state words): heap of 2G-1 digests, root first
-void host_merkle_top(const uint32_t* subroots, int G, std::vector<uint32_t>& heap) {
+void host_merkle_top(const uint32_t* subroots, int G, std::vector<uint32_t>& heap, int hash) {
     heap.assign((size_t)(2 * G - 1) * 8, 0);
     memcpy(heap.data() + (size_t)(G - 1) * 8, subroots, (size_t)G * 32);
-    for (int j = G - 2; j >= 0; --j) host_sha_inner(heap.data() + (size_t)(2 * j + 1) * 8, heap.data() + (size_t)(2 * j + 2) * 8, heap.data() + (size_t)j * 8);
+    for (int j = G - 2; j >= 0; --j) {
+        const uint32_t *l = heap.data() + (size_t)(2 * j + 1) * 8, *r = heap.data() + (size_t)(2 * j + 2) * 8;
+        if (hash == ZK_HASH_FIELD) {
+            Digest dl, dr;
+            memcpy(dl.w, l, 32); memcpy(dr.w, r, 32);
+            const Digest d = fieldhash_inner(dl, dr, host_fieldhash_consts());
+            memcpy(heap.data() + (size_t)j * 8, d.w, 32);
+        } else {
+            host_sha_inner(l, r, heap.data() + (size_t)j * 8);
+        }
+    }
+}
+// Consulted by the committer while it waits for a subtree's digests: the launch sits behind an all-to-all that never
+// completes when a peer has left the proof.
+int poll_peer_abort(void* user) {
+    zk_shard* s = static_cast<zk_shard*>(user);
+    if (!s->use_board) return 0;
+    const int ab = s->board.aborted_peer();
+    if (ab < 0 || ab == s->rank) return 0;
+    return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d", s->rank, s->G, ab, -(int)s->board.bad_code);
+}
+// A commit launch whose digests never arrived: with collectives the usual cause is a peer that never sent its piece.
+int commit_wait_failed(zk_shard* s, uint32_t lid, int rc) {
+    if (!collectives(s)) return rc;
+    const std::string inner = last_error();
+    const int ab = s->use_board ? s->board.aborted_peer() : -1;
+    if (ab >= 0 && ab != s->rank)
+        return fail(rc, "rank %d of %d: rank %d left the proof with error %d; the commitment of layer %u could not complete (%s)", s->rank, s->G, ab,
+                    -(int)s->board.bad_code, lid, inner.c_str());
+    return fail(rc, "rank %d of %d: the commitment of layer %u (all-to-all + subtree, before root exchange #%llu) did not complete: %s", s->rank, s->G,
+                lid, (unsigned long long)(s->board_seq + 1), inner.c_str());
 }
 
 // Cyclic layer `lid` (2^m_log values in total, 2^m_log / G here) -> subtree over this rank's block of leaves;
@@ -234,17 +321,17 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
             }
             for (uint32_t c = 0; c < K; ++c) {
                 HIPCHK(hipStreamWaitEvent(s->stream, s->ev_chunk[c], 0));
-                if ((rc = zk_dev_merkle_build_chunk(s->d_recv + (size_t)c * G * cc, lg, log_cnt - lk, nodes, m_log - lg, c, s->stream, ZK_HASH_SHA256))) return rc;
+                if ((rc = zk_dev_merkle_build_chunk(s->d_recv + (size_t)c * G * cc, lg, log_cnt - lk, nodes, m_log - lg, c, s->stream, s->hash))) return rc;
             }
-            if ((rc = zk_dev_merkle_commit_finish(s->committer, nodes, m_log - lg, lk, s->stream, ZK_HASH_SHA256, mine_bytes))) return rc;
+            if ((rc = zk_dev_merkle_commit_finish(s->committer, nodes, m_log - lg, lk, s->stream, s->hash, mine_bytes))) return commit_wait_failed(s, lid, rc);
             s->stats.chunked_layers += 1;
         } else {
             for (int g = 0; g < G; ++g) { send[g] = loc + (size_t)g * per; recv[g] = s->d_recv + (size_t)g * per; }
             if ((rc = all_to_all(s, send, recv, per, s->stream))) return rc;   // piece q: rank q's share of my block
-            if ((rc = zk_dev_merkle_commit(s->committer, s->d_recv, lg, log_cnt, nodes, s->stream, ZK_HASH_SHA256, mine_bytes))) return rc;
+            if ((rc = zk_dev_merkle_commit(s->committer, s->d_recv, lg, log_cnt, nodes, s->stream, s->hash, mine_bytes))) return commit_wait_failed(s, lid, rc);
         }
     } else {
-        if ((rc = zk_dev_merkle_commit(s->committer, loc, 0, m_log, nodes, s->stream, ZK_HASH_SHA256, mine_bytes))) return rc;
+        if ((rc = zk_dev_merkle_commit(s->committer, loc, 0, m_log, nodes, s->stream, s->hash, mine_bytes))) return rc;
     }
     // the G subtree roots, on the host of every rank
     uint32_t mine[8];
@@ -255,15 +342,20 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
     if (!collectives(s)) {
         memcpy(sub.data(), mine, 32);
     } else if (s->use_board) {
-        if (!s->board.exchange(++s->board_seq, mine, sub.data()))
-            return fail(ZK_ERR_HIP, "zk_shard: a rank did not post its subtree root (exchange %u timed out)", s->board_seq);
+        const RootBoard::Status bs = s->board.exchange(++s->board_seq, mine, sub.data(), s->timeout_s);
+        if (bs == RootBoard::kPeerAborted)
+            return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d (seen in root exchange #%llu, layer %u)", s->rank, G,
+                        s->board.bad_peer, -(int)s->board.bad_code, (unsigned long long)s->board_seq, lid);
+        if (bs != RootBoard::kOk)
+            return fail(ZK_ERR_HIP, "rank %d of %d: rank %d did not post its subtree root of layer %u (root exchange #%llu timed out after %.0f s)", s->rank, G,
+                        s->board.bad_peer, lid, (unsigned long long)s->board_seq, s->timeout_s);
     } else {
         if ((rc = all_gather(s, nodes, s->d_small, 8, s->stream))) return rc;   // node 0 of every rank's subtree
         HIPCHK(hipMemcpyAsync(s->h_small, s->d_small, 32 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
+        if ((rc = sync_peers(s, s->stream, "the all-gather of the subtree roots"))) return rc;
         memcpy(sub.data(), s->h_small, 32 * (size_t)G);
     }
-    host_merkle_top(sub.data(), G, s->tops[lid]);
+    host_merkle_top(sub.data(), G, s->tops[lid], s->hash);
     digest_words_to_bytes(s->tops[lid].data(), root_out);
     return ZK_OK;
 }
@@ -316,7 +408,7 @@ int decommit(zk_shard* s, Channel& ch, size_t x) {
     for (uint32_t j = 0; j < s->tail_rounds; ++j) tdig += 2 * (size_t)(L - rho0 - j);
     std::vector<uint8_t> tpaths(32 * tdig + 1);
     if ((rc = zk_tail_open(s->tail, x, tvals.data(), tpaths.data()))) return rc;
-    HIPCHK(hipStreamSynchronize(s->stream));
+    if ((rc = sync_peers(s, s->stream, "the all-gather of the decommitment"))) return rc;
     auto val_of = [&](size_t i) { return s->h_gall[(size_t)vit[i].owner * row * (collectives(s) ? 1 : 0) + i]; };
     std::vector<uint8_t> path;
     size_t dpos = 0;
@@ -363,7 +455,7 @@ int prove(zk_shard* s, Channel& ch) {
     s->info.public_last = s->last;
     s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
     s->stats.chunked_layers = 0;
-    ch.data.reserve(ch.data.size() + proof_data_len(s->log_n, s->log_b));
+    ch.data.reserve(ch.data.size() + proof_data_len(s->log_n, s->log_b, s->queries));
     if ((rc = do_lde(s))) return rc;                                              // prover.rs:60-70
     if ((rc = commit_sharded(s, 0, L, root))) return rc;                           // prover.rs:81
     ch.commit_hash(root);                                                          // prover.rs:85
@@ -395,11 +487,12 @@ int prove(zk_shard* s, Channel& ch) {
             if ((rc = all_gather(s, piece, s->d_gbuf, cnt, s->stream))) return rc;
             if ((rc = zk_dev_interleave(s->d_gbuf, s->d_repl, lg, m_log - 1 - lg, s->stream))) return rc;
             handed = s->d_repl;
+            if ((rc = sync_peers(s, s->stream, "the all-gather of the first replicated layer"))) return rc;   // zk_tail_run waits on this stream
         }
         zk_channel chan_view;                                                      // zk_tail_run drives the caller's channel
         chan_view.ch = std::move(ch);
         std::vector<uint8_t> troots(32 * ((size_t)s->tail_rounds + 1));
-        rc = zk_tail_run(s->tail, handed, s->stream, &chan_view, ZK_HASH_SHA256, s->info.beta_raw + rho0, troots.data(), &free_term);
+        rc = zk_tail_run(s->tail, handed, s->stream, &chan_view, s->hash, s->info.beta_raw + rho0, troots.data(), &free_term);
         ch = std::move(chan_view.ch);
         if (rc) return rc;
         for (uint32_t j = 0; j <= s->tail_rounds; ++j) memcpy(s->info.roots[1 + rho0 + j], troots.data() + 32 * j, 32);
@@ -407,8 +500,12 @@ int prove(zk_shard* s, Channel& ch) {
     (void)R;
     s->info.free_term = free_term;
     ch.commit_u32(free_term);                                                      // prover.rs:254
-    const uint32_t qraw = s->info.query_raw = ch.get_u32();                        // prover.rs:263
-    return decommit(s, ch, (size_t)qraw % (s->N - 2 * s->B));
+    uint32_t qraws[kMaxQueries];
+    for (uint32_t k = 0; k < s->queries; ++k) qraws[k] = ch.get_u32();            // prover.rs:263 (x queries)
+    s->info.query_raw = qraws[0];
+    for (uint32_t k = 0; k < s->queries; ++k)                                      // prover.rs:266-289 per query
+        if ((rc = decommit(s, ch, (size_t)qraws[k] % (s->N - 2 * s->B)))) return rc;
+    return ZK_OK;
 }
 
 template <typename T>
@@ -438,6 +535,8 @@ int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]) {
 int zk_shard_destroy(zk_shard* s) {
     if (!s) return ZK_OK;
     (void)hipSetDevice(s->device);
+    // after an error a collective may still sit on the streams waiting for a peer: abort the communicator first
+    if (s->comm && s->rccl && s->failed) { (void)s->rccl->CommAbort(s->comm); s->comm = nullptr; }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->xstream) (void)hipStreamSynchronize(s->xstream);
     if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
@@ -464,9 +563,10 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     *out = nullptr;
     auto t0 = std::chrono::steady_clock::now();
     if (int rc = check_proof_size("zk_shard_create", log_n, log_b)) return rc;
+    if (world < 1 || world > 32) return fail(ZK_ERR_INVALID, "zk_shard_create: world size %d out of range (1 .. 32)", world);
     uint32_t lg = 0;
     while ((1 << lg) < world) ++lg;
-    if (world < 1 || world > 32 || (1 << lg) != world || lg > log_b || rank < 0 || rank >= world)
+    if ((1 << lg) != world || lg > log_b || rank < 0 || rank >= world)
         return fail(ZK_ERR_INVALID, "zk_shard_create: world size %d must be a power of two dividing the blow-up %u, 0 <= rank < world", world, 1u << log_b);
     if (transport && (!transport->all_to_all || !transport->all_gather)) return fail(ZK_ERR_INVALID, "zk_shard_create: incomplete transport");
     if (!transport && !id) return fail(ZK_ERR_INVALID, "zk_shard_create: the RCCL transport needs the shared unique id (zk_shard_unique_id)");
@@ -483,6 +583,7 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         s->force = opt->force_collectives != 0;
     }
     if (getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1) s->overlap_min_log = 99;   // operational switch: plain collectives only
+    if (const char* e = getenv("ZK_SHARD_TIMEOUT_S")) { const double v = atof(e); if (v > 0) s->timeout_s = v; }
     int rc = ZK_OK;
     auto bail = [&](int code) { zk_shard_destroy(s); return code; };
 #define HIPCHK_S(expr)                                                                        \
@@ -519,6 +620,15 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         memcpy(&nid, id, sizeof nid);
         ncclResult_t r = s->rccl->CommInitRank(&s->comm, world, nid, rank);
         if (r != ncclSuccess) { s->comm = nullptr; return bail(fail(ZK_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, s->rccl->GetErrorString(r))); }
+        // did RCCL form the communicator this rank believes it is in?
+        int nr = -1, ur = -1;
+        ncclResult_t r1 = s->rccl->CommCount(s->comm, &nr), r2 = s->rccl->CommUserRank(s->comm, &ur);
+        if (r1 != ncclSuccess || r2 != ncclSuccess || nr != world || ur != rank) {
+            s->failed = true;                                    // zk_shard_destroy aborts the communicator
+            return bail(fail(ZK_ERR_HIP, "zk_shard_create: RCCL communicator mismatch: ncclCommCount = %d (expected %d), ncclCommUserRank = %d (expected %d)",
+                             nr, world, ur, rank));
+        }
+        s->stats.rccl_nranks = (uint32_t)nr;
         s->tp.user = s;
         s->tp.all_to_all = rccl_all_to_all;
         s->tp.all_gather = rccl_all_gather;
@@ -573,6 +683,7 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     }
     HIPCHK_S(hipStreamSynchronize(s->stream));
 #undef HIPCHK_S
+    if (s->use_board) committer_set_poll(s->committer, poll_peer_abort, s);
     s->stats.sharded_layers = ns;
     s->stats.root_board = s->use_board ? 1 : 0;
     s->stats.device_bytes = s->device_bytes;
@@ -599,14 +710,16 @@ int zk_shard_trace_upload(zk_shard* s, const uint32_t* trace, size_t count) {
 int zk_shard_prove_channel(zk_shard* s, zk_channel* chan) {
     if (!s || !chan) return fail(ZK_ERR_INVALID, "zk_shard_prove_channel: null argument");
     HIPCHK(hipSetDevice(s->device));
-    return prove(s, chan->ch);
+    if (s->failed) return fail(ZK_ERR_STATE, "zk_shard_prove_channel: this rank left an earlier proof with an error; destroy the prover");
+    return rank_failed(s, prove(s, chan->ch));
 }
 
 int zk_shard_prove(zk_shard* s, uint8_t* proof_out, size_t cap, size_t* proof_len, uint8_t state_out[32]) {
     if (!s || !proof_out || !state_out) return fail(ZK_ERR_INVALID, "zk_shard_prove: null argument");
     HIPCHK(hipSetDevice(s->device));
+    if (s->failed) return fail(ZK_ERR_STATE, "zk_shard_prove: this rank left an earlier proof with an error; destroy the prover");
     Channel ch;                                                // main.rs:19
-    int rc = prove(s, ch);
+    int rc = rank_failed(s, prove(s, ch));
     if (rc) return rc;
     if (proof_len) *proof_len = ch.data.size();
     if (ch.data.size() > cap) return fail(ZK_ERR_BUFFER, "zk_shard_prove: proof needs %zu bytes, buffer has %zu", ch.data.size(), cap);
@@ -621,9 +734,29 @@ int zk_shard_lde_commit(zk_shard* s, uint8_t root_out[32]) {
     HIPCHK(hipSetDevice(s->device));
     s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
     s->stats.chunked_layers = 0;
+    if (s->failed) return fail(ZK_ERR_STATE, "zk_shard_lde_commit: this rank left an earlier call with an error; destroy the prover");
     int rc = do_lde(s);                                         // prover.rs:60-70, each rank its cosets
     if (!rc) rc = commit_sharded(s, 0, s->L, root_out);         // the all-to-all transpose + prover.rs:81
-    return rc;
+    return rank_failed(s, rc);
+}
+
+// Merkle hash and number of queries: like zk_ctx_set_hash / zk_ctx_set_queries, the same on every rank.
+int zk_shard_set_hash(zk_shard* s, int hash_kind) {
+    if (!s) return fail(ZK_ERR_INVALID, "null prover");
+    if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_shard_set_hash: unknown hash %d", hash_kind);
+    s->hash = hash_kind;
+    return ZK_OK;
+}
+int zk_shard_set_queries(zk_shard* s, uint32_t n_queries) {
+    if (!s) return fail(ZK_ERR_INVALID, "null prover");
+    if (n_queries < 1 || n_queries > kMaxQueries) return fail(ZK_ERR_INVALID, "zk_shard_set_queries: need 1 <= n_queries <= %u", kMaxQueries);
+    s->queries = n_queries;
+    return ZK_OK;
+}
+// Test hook: this rank behaves as if its next proof had failed before the first collective (peers must not hang).
+int zk_shard_inject_failure(zk_shard* s, int code) {
+    if (!s) return fail(ZK_ERR_INVALID, "null prover");
+    return rank_failed(s, fail(code < 0 ? code : ZK_ERR_STATE, "injected failure on rank %d", s->rank));
 }
 
 int zk_shard_last_transcript(const zk_shard* s, zk_transcript_info* out) {

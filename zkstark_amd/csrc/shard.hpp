@@ -13,5 +13,8 @@ namespace impl {
 struct RcclApi;
 const RcclApi* rccl_api();                 // nullptr + fail() recorded when the library cannot be loaded
 
+// zkstark.hip: consulted by a committer while it waits for posted digests (non-zero return ends the wait)
+void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user);
+
 }  // namespace impl
 }  // namespace zk

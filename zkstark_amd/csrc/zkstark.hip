@@ -78,6 +78,10 @@ struct zk_ctx {
     bool tail = false;                  // FRI-tail context (zk_tail_*): no trace / LDE / composition
     uint32_t queries = 1;               // decommitment queries (1 = the reference, prover.rs:263)
     int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
+    // opt-in reference self-checks (zk_ctx_set_checks; prover.rs:64-66, :148-159, :169, :228-251)
+    bool checks = false;
+    uint32_t* d_check = nullptr;        // N words of scratch + 2 result words
+    DevTable ones;                      // powers of 1: the coefficient preparation without the coset shift
     size_t gather_cap = 0;
     size_t device_bytes = 0;
     double setup_ms = 0;
@@ -304,6 +308,75 @@ int do_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
 }
 
 
+// ---- opt-in reference self-checks ------------------------------------------------------------------------------
+// The reference asserts its way through generate_proof; with zk_ctx_set_checks(ctx, 1) the same checkpoints run here,
+// each on the layer as it sits in HBM, and the first one that fails is named (ZK_ERR_CHECK).
+int checks_alloc(zk_ctx* c) {
+    if (c->d_check) return ZK_OK;
+    int rc = dmalloc(c, &c->d_check, (c->N + 2) * 4);
+    if (rc) return rc;
+    return build_table(1, c->log_n, &c->ones);
+}
+// prover.rs:64-66: the interpolant passes through every trace point.  The coefficients (virtual-point correction and
+// 1/n as in coef_prepare, but no coset shift) are transformed forward over the TRACE group and compared with the trace.
+int check_interpolant(zk_ctx* c) {
+    const zk_dom* d = c->dom;
+    CoefPrepArgs pa{};
+    pa.log_n = d->log_n; pa.log_b = d->log_b;
+    pa.tw = d->H.view(); pa.wtab = c->ones.view(); pa.ninv_mont = d->ninv_mont;
+    pa.nd = d->plan.nd;
+    for (uint32_t t = 0; t < d->plan.nd; ++t) pa.dig_bits[t] = d->plan.bits[t];
+    HIPCHK(launch_coef_prepare(c->d_coef, c->d_check, pa, c->stream));          // d_coef[0..n) still holds the DIF output
+    int rc = run_dit(c->d_check, d->log_n, d->plan, d->H.view(), d->L, c->stream);
+    if (rc) return rc;
+    std::vector<uint32_t> got(c->n), want(c->n);
+    HIPCHK(hipMemcpyAsync(got.data(), c->d_check, c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(want.data(), c->d_trace, c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i + 1 < c->n; ++i)
+        if (got[i] != want[i])
+            return fail(ZK_ERR_CHECK, "self-check prover.rs:64-66 failed: f(g^%zu) = %u, trace value %u", i, got[i], want[i]);
+    return ZK_OK;
+}
+// Degree of the polynomial whose evaluations are `layer` (1 = cp_0, 2 + r = FRI layer r + 1) is exactly want_deg:
+// prover.rs:148-159 + :169 for cp (every division exact <=> deg cp = n - 1), :228-251 for the FRI layers.
+int check_degree(zk_ctx* c, uint32_t layer, uint32_t want_deg, const char* cite) {
+    const uint32_t lg = layer_log(c, layer);
+    const size_t m = (size_t)1 << lg;
+    const uint32_t* src = c->d_layers + c->layer_off[layer];
+    if (lg <= 10) {
+        // small layer: values to the host (or already there), plain inverse DFT of the coset-evaluations' sequence
+        std::vector<uint32_t> v(m);
+        if (c->tail_have && c->tail_log == lg && layer >= 2) v.assign(c->tail_vals.begin(), c->tail_vals.begin() + m);
+        else {
+            HIPCHK(hipMemcpyAsync(v.data(), src, m * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        const uint32_t winv = invmod(root_of_unity(lg));
+        for (size_t k = m; k-- > want_deg; ) {                    // coefficients of p(shift x), up to the factor m
+            uint32_t acc = 0, step = powmod(winv, k), x = 1;
+            for (size_t i = 0; i < m; ++i) { acc = add(acc, mulmod(v[i], x)); x = mulmod(x, step); }
+            if (k > want_deg && acc != 0)
+                return fail(ZK_ERR_CHECK, "self-check %s failed: layer %u has a non-zero coefficient of degree %zu > %u", cite, layer, k, want_deg);
+            if (k == want_deg && acc == 0)
+                return fail(ZK_ERR_CHECK, "self-check %s failed: layer %u has degree below %u", cite, layer, want_deg);
+        }
+        return ZK_OK;
+    }
+    const Plan pl = make_plan(lg);
+    int rc = run_dif(src, c->d_check, lg, pl, c->dom->Hinv.view(), c->dom->L, 0, c->stream);
+    if (rc) return rc;
+    uint32_t* res = c->d_check + c->N;
+    HIPCHK(hipMemsetAsync(res, 0, 8, c->stream));
+    HIPCHK(launch_degree_check(c->d_check, lg, pl.nd, pl.bits, want_deg + 1, res, c->stream));
+    uint32_t h[2];
+    HIPCHK(hipMemcpyAsync(h, res, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h[0]) return fail(ZK_ERR_CHECK, "self-check %s failed: layer %u has %u non-zero coefficients of degree > %u (a division left a remainder)", cite, layer, h[0], want_deg);
+    if (!h[1]) return fail(ZK_ERR_CHECK, "self-check %s failed: layer %u has degree below %u", cite, layer, want_deg);
+    return ZK_OK;
+}
+
 // generate_proof(channel) (prover.rs:9): everything is committed to, and every challenge drawn from, the
 // caller's channel `ch`, which may already hold a transcript prefix (main.rs:19 starts from a fresh one).
 int prove_resident(zk_ctx* c, Channel& ch) {
@@ -325,6 +398,7 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     c->info.public_last = c->last;
     begin_proof(c);
     if ((rc = do_lde(c))) return rc;                      // prover.rs:60-70
+    if (c->checks && ((rc = checks_alloc(c)) || (rc = check_interpolant(c)))) return rc;   // prover.rs:64-66
     if ((rc = do_merkle(c, 0, true))) return rc;          // prover.rs:81
     if ((rc = read_commit(c, 0, root))) return rc;
     ch.commit_hash(root);                                 // prover.rs:85
@@ -333,11 +407,13 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     for (int i = 0; i < 3; ++i) alpha[i] = c->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
     if ((rc = do_compose_commit(c, alpha))) return rc;    // prover.rs:166-176 (composition fused into the leaf hashing)
     if ((rc = read_commit(c, 1, root))) return rc;
+    if (c->checks && (rc = check_degree(c, 1, (uint32_t)c->n - 1, "prover.rs:148-159/:169 (exact divisions, deg cp = n - 1)"))) return rc;
     ch.commit_hash(root);                                 // prover.rs:180
     memcpy(c->info.roots[1], root, 32);
     for (uint32_t r = 0; r < R; ++r) {                    // prover.rs:198-225
         uint32_t beta = c->info.beta_raw[r] = ch.get_u32();   // prover.rs:200
         if ((rc = fri_round_commit(c, r, beta, root))) return rc;   // prover.rs:201-214 (fold fused into the leaf hashing)
+        if (c->checks && (rc = check_degree(c, 2 + r, (uint32_t)(c->n >> (r + 1)) - ((c->n >> (r + 1)) ? 1 : 0), "prover.rs:228-251 (FRI layer degree)"))) return rc;
         ch.commit_hash(root);                             // prover.rs:224
         memcpy(c->info.roots[2 + r], root, 32);
     }
@@ -539,6 +615,8 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (c->d_layers) (void)hipFree(c->d_layers);
     if (c->d_trees) (void)hipFree(c->d_trees);
     if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->d_check) (void)hipFree(c->d_check);
+    free_table(&c->ones);
     if (c->d_gather_off) (void)hipFree(c->d_gather_off);
     if (c->d_gather_out) (void)hipFree(c->d_gather_out);
     if (c->h_gather_off) (void)hipHostFree(c->h_gather_off);
@@ -582,6 +660,15 @@ int zk_ctx_get_host_levels(const zk_ctx* c, uint32_t* top_log, uint32_t* tail_lo
     if (!c || !top_log || !tail_log) return fail(ZK_ERR_INVALID, "zk_ctx_get_host_levels: null argument");
     *top_log = c->host_top;
     *tail_log = c->host_tail;
+    return ZK_OK;
+}
+// Opt-in: the reference's in-prover assertions (prover.rs:64-66 interpolant hits the trace, :148-159/:169 exact
+// divisions and deg cp = n - 1, :228-251 degree of every FRI layer) run inside zk_prove*; the first that fails is
+// named in a ZK_ERR_CHECK.  Costs a forward transform of the interpolant and one inverse transform per layer.
+int zk_ctx_set_checks(zk_ctx* c, int on) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    if (c->tail) return fail(ZK_ERR_STATE, "zk_ctx_set_checks: FRI-tail context");
+    c->checks = on != 0;
     return ZK_OK;
 }
 int zk_ctx_set_hash(zk_ctx* c, int hash_kind) {
@@ -1043,7 +1130,15 @@ struct zk_committer {
     // its completion is awaited (an event, normally long signalled) before the next commit overwrites the buffer
     hipEvent_t stage_free = nullptr;
     bool stage_busy = false;
+    // optional: consulted while waiting for the posted digests (shard.hip: has a peer left the proof?)
+    int (*poll)(void*) = nullptr;
+    void* poll_user = nullptr;
 };
+extern "C++" {
+namespace zk { namespace impl {
+void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user) { if (k) { k->poll = poll; k->poll_user = user; } }
+} }
+}
 int zk_committer_destroy(zk_committer* k) {
     if (!k) return ZK_OK;
     (void)hipSetDevice(k->device);
@@ -1080,7 +1175,7 @@ int zk_committer_create(int device, zk_committer** out) {
 // Waits for the digests a commit launch posted; with a hand-over depth, hashes the levels above on this thread
 // and queues the copy of those nodes into d_nodes.
 static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nodes, hipStream_t s, uint8_t root_out[32]) {
-    int rc = wait_flag(k->h_mail, m.seq, s);
+    int rc = wait_flag(k->h_mail, m.seq, s, k->poll, k->poll_user);
     if (rc) return rc;
     if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
     const size_t cnt = (size_t)1 << m.top;

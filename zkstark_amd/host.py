@@ -318,6 +318,10 @@ class Context:
     def set_host_levels(self, top_log, tail_log):
         check(_lib.load().zk_ctx_set_host_levels(self._h, top_log, tail_log))
 
+    def set_checks(self, on=True):
+        """The reference's in-prover assertions (prover.rs:64-66, :148-159/:169, :228-251) inside prove()."""
+        check(_lib.load().zk_ctx_set_checks(self._h, int(on)))
+
     def last_transcript(self):
         info = _lib.TranscriptInfo()
         check(_lib.load().zk_last_transcript(self._h, C.byref(info)))
@@ -416,14 +420,19 @@ class ShardContext:
     library) with the shared `unique_id`; a _lib.ShardTransport supplies the caller's own collectives."""
 
     def __init__(self, log_n, log_blowup, rank, world, unique_id=None, device=0, transport=None, min_layer_log=0, min_chunk_log=0,
-                 overlap_min_log=0, force_collectives=False, no_root_board=False):
+                 overlap_min_log=0, force_collectives=False, no_root_board=False, hash="sha256", queries=1):
         self.log_n, self.log_blowup, self.rank, self.world = log_n, log_blowup, rank, world
+        self.hash, self.queries = hash, queries
         self._transport = transport                      # keeps the callbacks alive
         opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), int(no_root_board))
         self._h = C.c_void_p()
         idb = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         check(_lib.load().zk_shard_create(device, rank, world, idb, C.byref(transport) if transport is not None else None,
                                           C.byref(opt), log_n, log_blowup, C.byref(self._h)))
+        if hash != "sha256":
+            check(_lib.load().zk_shard_set_hash(self._h, HASHES[hash]))
+        if queries != 1:
+            check(_lib.load().zk_shard_set_queries(self._h, queries))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -440,10 +449,14 @@ class ShardContext:
         check(_lib.load().zk_shard_trace_upload(self._h, _ptr(t), len(t)))
 
     def prove(self):
-        cap = _lib.load().zk_proof_data_len(self.log_n, self.log_blowup)
+        cap = _lib.load().zk_proof_data_len_queries(self.log_n, self.log_blowup, self.queries)
         buf, st, n = C.create_string_buffer(cap), C.create_string_buffer(32), C.c_size_t()
         check(_lib.load().zk_shard_prove(self._h, buf, cap, C.byref(n), st))
-        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, self.last_transcript().public_last)
+        return Proof(st.raw, buf.raw[:n.value], self.log_n, self.log_blowup, self.last_transcript().public_last, self.hash, self.queries)
+
+    def inject_failure(self, code=-4):
+        """Test hook (zk_shard_inject_failure): this rank leaves the protocol with an error; peers must not hang."""
+        return _lib.load().zk_shard_inject_failure(self._h, code)
 
     def prove_channel(self, channel):
         check(_lib.load().zk_shard_prove_channel(self._h, channel._h))
