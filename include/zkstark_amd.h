@@ -309,6 +309,24 @@ typedef struct zk_shard_stats {
     double setup_ms;
     double device_bytes;
 } zk_shard_stats;
+/* The layout of a sharded proof, as a pure function of its arguments (no GPU, no communication): what
+ * zk_shard_create will do.  Layer ids: 0 = f_eval, 1 + r = FRI layer r. */
+typedef struct zk_shard_plan_info {
+    uint32_t world;
+    uint32_t log_world;
+    uint32_t sharded_layers;     /* FRI layers 0 .. sharded_layers-1 (and f) are distributed */
+    uint32_t tail_rounds;        /* FRI rounds of the replicated tail */
+    uint32_t chunked_layers;     /* committed layers exchanged in chunks overlapped with the hashing */
+    uint32_t chunked_mask;       /* bit id set: layer id is exchanged in chunks */
+    uint32_t log_chunks;         /* a chunked layer is exchanged in 2^log_chunks chunks */
+    uint32_t min_layer_log;      /* the thresholds in force (options, defaults, ZK_SHARD_PLAIN) */
+    uint32_t min_chunk_log;
+    uint32_t overlap_min_log;
+    uint32_t piece_log[32];      /* log2 words of one (rank, peer) piece of layer id */
+    double all_to_all_bytes;     /* bytes one rank sends to its peers in the all-to-alls of one proof */
+    double lde_commit_bytes;     /* ... of zk_shard_lde_commit (layer 0 only) */
+} zk_shard_plan_info;
+int zk_shard_plan(int world, uint32_t log_n, uint32_t log_blowup, const zk_shard_options *opt, zk_shard_plan_info *out);
 /* ncclGetUniqueId through the same run-time loaded RCCL (rank 0, before zk_shard_create). */
 int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]);
 /* Collective over the `world` ranks (ncclCommInitRank when transport is NULL).  id: the shared 128 bytes; with a

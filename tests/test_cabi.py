@@ -225,3 +225,30 @@ def test_multi_query_proofs(zk, orc):
                 zk.Proof(r.state, bytes(bad), 6, 2, r.public_last, queries=q).verify()
     finally:
         orc.set_queries(1)
+
+
+def test_shard_plan_is_the_one_layout(zk):
+    """zk_shard_plan (no GPU): the layout both the native sharded prover and the torch.distributed mirror follow.
+    The benchmark's weak-scaling configurations, the byte formula of DESIGN.md section 6, and the mirror's view of it."""
+    # bench.py --gpus 2 / 4 / 8 (2^24 elements per GPU, production thresholds): GPU tests assert the same numbers on the prover's stats
+    for world, log_n, want_sharded, want_chunked in ((2, 22, 4, 3), (4, 23, 5, 2), (8, 24, 6, 0), (8, 21, 3, 0), (1, 21, 3, 0)):
+        pl = zk.shard_plan(world, log_n, 3)
+        assert (pl["sharded_layers"], pl["chunked_layers"]) == (want_sharded, want_chunked), (world, log_n, pl)
+        assert pl["tail_rounds"] == log_n - want_sharded and pl["log_chunks"] == 2
+        N = 1 << (log_n + 3)
+        words = N + sum(N >> rho for rho in range(want_sharded))          # f and FRI layers 0 .. ns-1: one all-to-all each
+        assert pl["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world
+        assert pl["lde_commit_bytes"] == 4.0 * N / world * (world - 1) / world
+        assert pl["piece_log"][0] == log_n + 3 - 2 * pl["log_world"]
+    # explicit thresholds; at least one round stays in the replicated tail; a chunked layer needs pieces of >= 2^10 words
+    pl = zk.shard_plan(2, 6, 3, min_layer_log=1, min_chunk_log=1)
+    assert pl["sharded_layers"] == 5 and pl["tail_rounds"] == 1
+    pl = zk.shard_plan(2, 9, 3, min_layer_log=1, min_chunk_log=3, overlap_min_log=3)
+    assert pl["chunked_mask"] & 1 and pl["piece_log"][0] == 10 and not (pl["chunked_mask"] >> 2) & 1
+    for bad in ((3, 12, 3), (16, 12, 3), (2, 3, 3), (4, 4, 2)):
+        with pytest.raises(zk.ZkError) as e:
+            zk.shard_plan(*bad)
+        assert e.value.code == -1
+    # the mirror holds no thresholds of its own
+    src = open(os.path.join(ROOT, "zkstark_amd", "sharded.py")).read()
+    assert "shard_plan(" in src and "chunk_min_log" not in src

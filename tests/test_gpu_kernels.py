@@ -187,16 +187,23 @@ def test_reference_self_checks(zk, orc, log_n, log_b):
         assert ctx.prove(a).data == want.proof            # and the context is still good
 
 
-def test_self_checks_catch_a_wrong_layer(zk):
-    """The degree checkpoints look at the layers in HBM: a single value of cp_0 overwritten after the fact is seen by
-    the checker of prover.rs:169 (used here through the stage API: compose, corrupt, re-check by proving is not possible,
-    so the check is driven the way the prover drives it: a corrupted FRI input makes the NEXT layer's degree wrong)."""
-    log_n, log_b = 12, 3
-    with zk.Context(log_n, log_b, host_levels=(0, 0)) as ctx:
+@pytest.mark.parametrize("host_levels,hash_name", [((0, 0), "sha256"), ((8, 9), "sha256"), ((5, 6), "sha256"), (None, "field")])
+def test_self_checks_with_every_division_of_labour(zk, orc, host_levels, hash_name):
+    """The checkpoints read the layers where they are: all on the device (host_levels (0, 0)), small FRI layers on the
+    host thread (the default), other hand-over depths, and with the field hash.  A good trace passes all of them and
+    the proof bytes do not change."""
+    log_n, log_b = 13, 3
+    a = zk.trace_fibsq((1 << log_n) - 1)
+    with zk.Context(log_n, log_b, hash=hash_name, host_levels=host_levels) as ctx:
+        plain = ctx.prove(a)
         ctx.set_checks(True)
-        ctx.prove(zk.trace_fibsq((1 << log_n) - 1))       # passes
-    # the interpolant check (prover.rs:64-66) compares with the trace in HBM: nothing to corrupt from outside; it is
-    # exercised on every good proof above (all n - 1 points)
+        checked = ctx.prove(a)
+        assert checked.data == plain.data and checked.state == plain.state
+        bad = a.copy()
+        bad[77] = (int(bad[77]) + 5) % P
+        with pytest.raises(zk.ZkError) as e:
+            ctx.prove(bad)
+        assert e.value.code == -7 and "prover.rs:148-159/:169" in str(e.value)
 
 
 def test_prove_channel_uses_the_callers_channel(zk, orc):

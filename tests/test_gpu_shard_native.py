@@ -212,6 +212,10 @@ def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
         assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world
         if "overlap_min_log" in opts:
             assert st["chunked_layers"] >= 2
+        # what ran is what zk_shard_plan announced (the one layout, shared with the mirror)
+        import zkstark_amd as zk
+        pl = zk.shard_plan(world, log_n, log_b, **{k: v for k, v in opts.items() if k in ("min_layer_log", "min_chunk_log", "overlap_min_log")})
+        assert (st["sharded_layers"], st["chunked_layers"], st["all_to_all_bytes"]) == (pl["sharded_layers"], pl["chunked_layers"], pl["all_to_all_bytes"])
 
 
 def test_shard_two_ranks_production_sizes_2e25(orc):

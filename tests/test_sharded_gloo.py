@@ -118,7 +118,8 @@ def _chunk_worker(rank, world, port, log_n, log_b, lists, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,log_b,lists", [(2, 8, 3, True), (4, 10, 2, True), (8, 11, 3, True), (2, 8, 3, False), (4, 10, 2, False)])
+# sizes: a layer is exchanged in chunks when a (rank, peer) piece has >= 2^10 words (zk_shard_plan), whatever overlap_min_log says
+@pytest.mark.parametrize("world,log_n,log_b,lists", [(2, 9, 3, True), (4, 12, 2, True), (8, 13, 3, True), (2, 9, 3, False), (4, 12, 2, False)])
 def test_chunked_exchange_multirank(orc, world, log_n, log_b, lists):
     """The chunked commitment of the N > 1 path with real collectives between CPU ranks: hashing chunk c while
     chunk c+1 is exchanged, either as list exchanges over slices of the layer (what RCCL runs; emulated with

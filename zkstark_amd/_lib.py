@@ -55,6 +55,13 @@ class ChainProbe(C.Structure):
                 ("waves_per_simd", C.c_uint32), ("launches", C.c_uint32), ("hashes", C.c_uint32), ("cus", C.c_uint32)]
 
 
+class ShardPlan(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("log_world", C.c_uint32), ("sharded_layers", C.c_uint32), ("tail_rounds", C.c_uint32),
+                ("chunked_layers", C.c_uint32), ("chunked_mask", C.c_uint32), ("log_chunks", C.c_uint32), ("min_layer_log", C.c_uint32),
+                ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32), ("piece_log", C.c_uint32 * 32),
+                ("all_to_all_bytes", C.c_double), ("lde_commit_bytes", C.c_double)]
+
+
 KERNEL_CLASSES = ("ntt", "merkle_leaf", "merkle_inner", "merkle_top", "compose", "fri_fold", "gather")
 
 
@@ -154,6 +161,7 @@ SYMBOLS = {
     "zk_tail_create": (_int, [_int, _u32, _u32, _u32, C.POINTER(_vp)]),
     "zk_tail_run": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_u32)]),
     "zk_tail_open": (_int, [_vp, _sz, _vp, _vp]),
+    "zk_shard_plan": (_int, [_int, _u32, _u32, C.POINTER(ShardOptions), C.POINTER(ShardPlan)]),
     "zk_shard_unique_id": (_int, [_vp]),
     "zk_shard_create": (_int, [_int, _int, _int, _vp, C.POINTER(ShardTransport), C.POINTER(ShardOptions), _u32, _u32, C.POINTER(_vp)]),
     "zk_shard_destroy": (_int, [_vp]),
@@ -183,15 +191,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    want = _build.source_hash()
+    # The authority on what a binary was built from is the hash compiled into it (zk_build_hash); the git-ignored
+    # sidecar file only saves a dlopen when deciding whether to rebuild.
+    want, build_err = None, None
     try:
+        want = _build.source_hash()          # needs csrc/: absent in a deployment that ships only the .so
         _build.build()                       # rebuilds (under a lock) when the library is missing or built from other sources
-    except Exception as e:                   # no hipcc on this box: only a library built from THIS tree will do
+    except Exception as e:                   # no sources, or no hipcc on this box: only an existing library will do
+        build_err = e
         if not os.path.exists(LIB_PATH):
-            raise ImportError(f"libzkstark_amd.so is missing and cannot be built: {e}") from e
-        if _build.built_hash() != want and os.environ.get("ZK_ALLOW_STALE_LIB") != "1":
-            raise ImportError(f"libzkstark_amd.so was built from other sources ({_build.built_hash()} != {want}) "
-                              f"and cannot be rebuilt here: {e}") from e
+            raise ImportError(f"libzkstark_amd.so is missing and cannot be built here: {e}") from e
     # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME
     # libamdhip64.so.7); if it is loaded first the dynamic loader resolves this library's
     # libamdhip64.so.7 to the same object, so torch tensors, streams and RCCL interoperate with
@@ -205,8 +214,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
     got = lib.zk_build_hash().decode()
-    if got != want and os.environ.get("ZK_ALLOW_STALE_LIB") != "1":
-        raise ImportError(f"libzkstark_amd.so is stale: built from {got}, the tree is {want} (python -m zkstark_amd.build)")
+    if want is not None and got != want and os.environ.get("ZK_ALLOW_STALE_LIB") != "1":
+        why = f" and cannot be rebuilt here: {build_err}" if build_err is not None else " (python -m zkstark_amd.build)"
+        raise ImportError(f"libzkstark_amd.so is stale: built from {got}, the tree is {want}{why}")
     _lib = lib
     return lib
 

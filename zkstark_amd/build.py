@@ -44,10 +44,26 @@ def source_hash():
 
 
 def built_hash():
-    """Hash the existing library was built from (sidecar written by the build), or None."""
+    """Hash the existing library was built from, or None.  The authority is the string compiled into the binary
+    (version.cpp: "zkstark_amd.build_hash=<hash>", also what zk_build_hash() returns); the git-ignored sidecar file is
+    only a shortcut and is not needed."""
+    if not os.path.exists(LIB):
+        return None
     try:
         with open(HASHFILE) as f:
-            return f.read().strip() if os.path.exists(LIB) else None
+            side = f.read().strip()
+        if side and os.path.getmtime(HASHFILE) >= os.path.getmtime(LIB):
+            return side
+    except OSError:
+        pass
+    try:
+        with open(LIB, "rb") as f:
+            blob = f.read()
+        i = blob.find(b"zkstark_amd.build_hash=")
+        if i < 0:
+            return None
+        tail = blob[i + len(b"zkstark_amd.build_hash="):i + len(b"zkstark_amd.build_hash=") + 64]
+        return tail.split(b"\0", 1)[0].decode("ascii", "replace") or None
     except OSError:
         return None
 

@@ -115,7 +115,7 @@ struct zk_shard {
     // layout
     uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 22;
     static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
-    uint32_t n_sharded = 1, tail_rounds = 0;
+    uint32_t n_sharded = 1, tail_rounds = 0, chunked_mask = 0;   // zk_shard_plan
     zk_dom* dom_loc = nullptr;
     zk_ctx* tail = nullptr;
     zk_committer* committer = nullptr;
@@ -304,7 +304,7 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
         const size_t per = cnt >> lg;
         const uint32_t* send[64];
         uint32_t* recv[64];
-        if (log_cnt >= s->overlap_min_log && log_cnt >= zk_shard::kLogChunks + 8) {
+        if ((s->chunked_mask >> lid) & 1u) {                      // zk_shard_plan: pieces of >= 2^overlap_min_log words
             // big layer: exchange and hash in K aligned chunks, so that hashing chunk c overlaps the exchange of
             // chunk c+1.  The exchanges are issued from a side stream that depends on the layer only.
             const uint32_t lk = zk_shard::kLogChunks, K = 1u << lk;
@@ -532,6 +532,58 @@ int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]) {
     return ZK_OK;
 }
 
+// The layout of a sharded proof as a pure function of (world, sizes, options): which FRI layers stay distributed,
+// which of them are exchanged in chunks, and the bytes every rank sends to its peers.  zk_shard_create uses it, and so
+// does the torch.distributed mirror (zkstark_amd/sharded.py), so the two cannot drift apart.  No GPU needed.
+int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_options* opt, zk_shard_plan_info* out) {
+    if (!out) return fail(ZK_ERR_INVALID, "zk_shard_plan: out is null");
+    memset(out, 0, sizeof *out);
+    if (int rc = check_proof_size("zk_shard_plan", log_n, log_b)) return rc;
+    if (world < 1 || world > 32) return fail(ZK_ERR_INVALID, "zk_shard_plan: world size %d out of range (1 .. 32)", world);
+    uint32_t lg = 0;
+    while ((1 << lg) < world) ++lg;
+    if ((1 << lg) != world || lg > log_b)
+        return fail(ZK_ERR_INVALID, "zk_shard_plan: world size %d must be a power of two dividing the blow-up %u", world, 1u << log_b);
+    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 22;
+    bool force = false;
+    if (opt) {
+        if (opt->min_layer_log) min_layer_log = opt->min_layer_log;
+        if (opt->min_chunk_log) min_chunk_log = opt->min_chunk_log;
+        if (opt->overlap_min_log) overlap_min_log = opt->overlap_min_log;
+        force = opt->force_collectives != 0;
+    }
+    if (getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1) overlap_min_log = 99;   // operational switch: plain collectives only
+    const uint32_t L = log_n + log_b, R = log_n;
+    if (L < 2 * lg + min_chunk_log)
+        return fail(ZK_ERR_INVALID, "zk_shard_plan: domain 2^%u is too small to shard over %d ranks: use zk_prove", L, world);
+    // FRI layer rho (2^(L-rho) values) stays distributed while it has >= 2^min_layer_log values and a (rank, peer)
+    // piece has >= 2^min_chunk_log leaves; layer 0 (cp) is always distributed, like f; at least one round is left
+    // to the replicated tail (the last layers are tiny)
+    uint32_t ns = 0;
+    for (uint32_t rho = 0; rho <= R; ++rho)
+        if (L - rho >= min_layer_log && L - rho >= 2 * lg + min_chunk_log) ++ns;
+    if (ns < 1) ns = 1;
+    if (ns > R - 1) ns = R - 1;
+    out->world = (uint32_t)world; out->log_world = lg;
+    out->sharded_layers = ns;
+    out->tail_rounds = R - ns;
+    out->min_layer_log = min_layer_log; out->min_chunk_log = min_chunk_log; out->overlap_min_log = overlap_min_log;
+    out->log_chunks = zk_shard::kLogChunks;
+    const bool coll = world > 1 || force;
+    // committed distributed layers: id 0 = f, id 1 + rho = FRI layer rho < ns; layer id has 2^m_log values in total
+    for (uint32_t lid = 0; lid <= ns && lid < 32; ++lid) {
+        const uint32_t m_log = lid == 0 ? L : L - (lid - 1);
+        const uint32_t log_cnt = m_log - 2 * lg;                     // words per (rank, peer) piece
+        const bool chunked = coll && log_cnt >= overlap_min_log && log_cnt >= zk_shard::kLogChunks + 8;
+        out->piece_log[lid] = log_cnt;
+        if (chunked) { out->chunked_mask |= 1u << lid; out->chunked_layers += 1; }
+        const double sent = coll ? 4.0 * (double)((size_t)1 << log_cnt) * (world - 1) : 0.0;   // to the world - 1 peers
+        out->all_to_all_bytes += sent;
+        if (lid == 0) out->lde_commit_bytes = sent;
+    }
+    return ZK_OK;
+}
+
 int zk_shard_destroy(zk_shard* s) {
     if (!s) return ZK_OK;
     (void)hipSetDevice(s->device);
@@ -582,7 +634,6 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         if (opt->overlap_min_log) s->overlap_min_log = opt->overlap_min_log;
         s->force = opt->force_collectives != 0;
     }
-    if (getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1) s->overlap_min_log = 99;   // operational switch: plain collectives only
     if (const char* e = getenv("ZK_SHARD_TIMEOUT_S")) { const double v = atof(e); if (v > 0) s->timeout_s = v; }
     int rc = ZK_OK;
     auto bail = [&](int code) { zk_shard_destroy(s); return code; };
@@ -595,17 +646,14 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         }                                                                                     \
     } while (0)
     const uint32_t L = s->L, R = s->R;
-    if (L < 2 * lg + s->min_chunk_log) return bail(fail(ZK_ERR_INVALID, "zk_shard_create: domain 2^%u is too small to shard over %d ranks: use zk_prove", L, world));
-    // FRI layer rho (2^(L-rho) values) stays distributed while it has >= 2^min_layer_log values and a (rank, peer)
-    // piece has >= 2^min_chunk_log leaves; layer 0 (cp) is always distributed, like f; at least one round is left
-    // to the replicated tail (the last layers are tiny)
-    uint32_t ns = 0;
-    for (uint32_t rho = 0; rho <= R; ++rho)
-        if (L - rho >= s->min_layer_log && L - rho >= 2 * lg + s->min_chunk_log) ++ns;
-    if (ns < 1) ns = 1;
-    if (ns > R - 1) ns = R - 1;
+    zk_shard_plan_info plan;
+    if ((rc = zk_shard_plan(world, log_n, log_b, opt, &plan))) return bail(rc);
+    s->min_layer_log = plan.min_layer_log; s->min_chunk_log = plan.min_chunk_log; s->overlap_min_log = plan.overlap_min_log;
+    const uint32_t ns = plan.sharded_layers;
     s->n_sharded = ns;
-    s->tail_rounds = R - ns;
+    s->tail_rounds = plan.tail_rounds;
+    s->chunked_mask = plan.chunked_mask;
+    (void)R;
     HIPCHK_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIPCHK_S(hipStreamCreateWithFlags(&s->xstream, hipStreamNonBlocking));
     HIPCHK_S(hipEventCreateWithFlags(&s->ev_layer, hipEventDisableTiming));

@@ -6,7 +6,10 @@
 #define ZK_SRC_HASH "unknown"
 #endif
 
+// The hash sits behind a marker so that build.py can read it from the file without loading the library.
+static const char kBuildTag[] = "zkstark_amd.build_hash=" ZK_SRC_HASH;
+
 extern "C" {
-const char* zk_version(void) { return "zkstark_amd 0.2 (gfx950)"; }
-const char* zk_build_hash(void) { return ZK_SRC_HASH; }
+const char* zk_version(void) { return "zkstark_amd 0.3 (gfx950)"; }
+const char* zk_build_hash(void) { return kBuildTag + sizeof("zkstark_amd.build_hash=") - 1; }
 }

@@ -407,6 +407,16 @@ class BatchContext:
                 for p in range(self.batch)]
 
 
+def shard_plan(world, log_n, log_blowup, min_layer_log=0, min_chunk_log=0, overlap_min_log=0, force_collectives=False):
+    """zk_shard_plan: the layout zk_shard_create would choose (no GPU needed); a dict of the zk_shard_plan_info fields."""
+    opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), 0)
+    pl = _lib.ShardPlan()
+    check(_lib.load().zk_shard_plan(world, log_n, log_blowup, C.byref(opt), C.byref(pl)))
+    d = {k: getattr(pl, k) for k, _ in _lib.ShardPlan._fields_ if k != "piece_log"}
+    d["piece_log"] = list(pl.piece_log)[:pl.sharded_layers + 1]
+    return d
+
+
 def shard_unique_id():
     """ncclGetUniqueId (rank 0): the 128 bytes every rank hands to ShardContext."""
     buf = C.create_string_buffer(128)

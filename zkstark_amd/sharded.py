@@ -396,12 +396,15 @@ class ShardedProver:
         self.L = log_n + log_blowup
         self.R = log_n
         self.n, self.N, self.B = 1 << log_n, 1 << self.L, 1 << log_blowup
-        # FRI layer rho (2^(L-rho) values) stays sharded while it has >= 2^min_layer_log values and a
-        # (rank, peer) chunk has >= 2^min_chunk_log leaves; layer 0 (cp) is always sharded, like f
-        if self.L - 2 * self.lg < min_chunk_log:
-            raise ZkError(-1, "domain too small to shard: use the single-GPU prover")
-        self.n_sharded = max(1, sum(1 for rho in range(self.R + 1)
-                                    if self.L - rho >= min_layer_log and self.L - rho - 2 * self.lg >= min_chunk_log))
+        # Which layers stay distributed and which are exchanged in chunks is NOT decided here: zk_shard_plan (csrc/shard.hip)
+        # is the one statement of the layout, shared with the native prover (in zk_shard_options 0 selects the default, so the
+        # smallest explicit threshold is 1: pieces of two leaves).
+        from .host import shard_plan
+        plan = shard_plan(G, log_n, log_blowup, min_layer_log=max(min_layer_log, 1), min_chunk_log=max(min_chunk_log, 1),
+                          overlap_min_log=overlap_min_log, force_collectives=bool(getattr(comm, "force", False)))
+        self.plan = plan
+        self.n_sharded = plan["sharded_layers"]
+        self.chunked_mask = plan["chunked_mask"]
         h = root_of_unity(self.L)
         self.shift = GEN_W * _pow(h, self.rank) % P
         be = self.be
@@ -430,7 +433,7 @@ class ShardedProver:
         self.recv = be.empty(NL)
         self.block = be.empty(NL)
         self.subroot_all = be.empty(8 * G)
-        self.log_chunks, self.chunk_min_log = 2, max(overlap_min_log, 2 + 6)   # layers with >= 2^22 words per (rank, peer): 4 chunks
+        self.log_chunks = plan["log_chunks"]                     # chunked layers (plan["chunked_mask"]): 2^log_chunks chunks
         # the first replicated layer arrives as G cyclic pieces before it is interleaved
         self.gbuf = be.empty(max(1, self.N >> self.n_sharded)) if self.n_sharded <= self.R else None
         self.have_trace = False
@@ -480,7 +483,7 @@ class ShardedProver:
         recv, block = self.recv[:cnt], self.block[:cnt]
         nodes = self._tree(lid)
         log_cnt = m_log - 2 * lg                                  # words per (rank, peer) chunk
-        if (G > 1 or self.comm.force) and hasattr(be, "merkle_chunk") and log_cnt >= self.chunk_min_log:
+        if (G > 1 or self.comm.force) and hasattr(be, "merkle_chunk") and (self.chunked_mask >> lid) & 1:
             # big layer: exchange and hash in K aligned chunks, so that hashing chunk c overlaps the
             # all-to-all of chunk c+1 (the exchange runs on RCCL's stream)
             K, lk = 1 << self.log_chunks, self.log_chunks
