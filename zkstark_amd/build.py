@@ -25,6 +25,8 @@ HEADERS = ["field.hpp", "sha256.hpp", "fieldhash.hpp", "kernels.hpp", "transcrip
            "shard.hpp", "board.hpp", os.path.join("..", "..", "include", "zkstark_amd.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
+# build-time experiments (e.g. ZK_BUILD_DEFS="-DZK_MONT_VARIANT=4"): part of the flags, hence of the source hash
+FLAGS += os.environ.get("ZK_BUILD_DEFS", "").split()
 
 
 def _read(rel):

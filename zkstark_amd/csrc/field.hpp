@@ -33,16 +33,47 @@ constexpr uint32_t P_INV = 0x40000001u;    // P * P_INV == 1 (mod 2^32)
 constexpr uint32_t R1 = 1073741823u;       // 2^32 mod P   (Montgomery form of 1)
 constexpr uint32_t GEN_W = 5u;             // smallest primitive root (field.rs:52-86, prover.rs:44)
 
+// Build-time variants of the reduction tails (tools/ab_field_variants.sh measures them in the real kernels):
+//   ZK_MONT_VARIANT 2 (default): borrow of the subtract (v_sub_co_u32) selects the correction     -- 6 VALU
+//   ZK_MONT_VARIANT 4: v_cmp_lt_u32 + v_cndmask(0, P) + v_add, simple ops only after the multiplies -- 7 VALU
+//   ZK_MONT_VARIANT 0: round 2's form (the compiler compares the 64-bit halves)                     -- 8 VALU
+//   ZK_ADDSUB_CMP 1: add / sub select the correction with v_cmp_lt_u32 instead of the subtract's borrow
+#ifndef ZK_MONT_VARIANT
+#define ZK_MONT_VARIANT 2
+#endif
+#ifndef ZK_ADDSUB_CMP
+#define ZK_ADDSUB_CMP 0
+#endif
+
+// P if a < b else 0, from a 32-bit compare (device: one v_cmp_lt_u32 + one v_cndmask_b32, no carry-out instruction)
+ZK_HD uint32_t p_if_less(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t c;
+    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(c) : "v"(a), "v"(b), "v"(P) : "vcc");
+    return c;
+#else
+    return a < b ? P : 0u;
+#endif
+}
+
 // field.rs:99-111
 ZK_HD uint32_t add(uint32_t a, uint32_t b) {
     uint32_t nb = P - b;            // in (0, P]
     uint32_t d = a - nb;            // a + b - P (mod 2^32)
+#if ZK_ADDSUB_CMP
+    return d + p_if_less(a, nb);
+#else
     return a < nb ? d + P : d;      // a + b < P  ->  a + b
+#endif
 }
 // field.rs:113-132
 ZK_HD uint32_t sub(uint32_t a, uint32_t b) {
     uint32_t d = a - b;
+#if ZK_ADDSUB_CMP
+    return d + p_if_less(a, b);
+#else
     return a < b ? d + P : d;
+#endif
 }
 // field.rs:198-203
 ZK_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
@@ -50,9 +81,8 @@ ZK_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 // Montgomery product a*b*R^-1 mod P, result canonical in [0, P).
 // Requires a*b < P*2^32, i.e. at least one operand < P (the other may be any u32,
 // which is how raw u32 challenges >= P are absorbed: field.rs:20-24).
-// Written so that hipcc emits six VALU instructions: v_mad_u64_u32 (lo and hi of a*b in one four-cycle op),
-// v_lshl_add_u32, v_mul_hi_u32, v_sub_co_u32 (the borrow IS the comparison), v_add_u32, v_cndmask_b32.  Comparing
-// `hi < mp_hi` instead costs a 64-bit compare and two moves more (tools/montmul_probe.hip).
+// Default form: hipcc emits six VALU instructions: v_mad_u64_u32 (lo and hi of a*b in one four-cycle op),
+// v_lshl_add_u32, v_mul_hi_u32, v_sub_co_u32 (the borrow IS the comparison), v_add_u32, v_cndmask_b32.
 ZK_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umulhi(a, b);
@@ -60,13 +90,26 @@ ZK_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
+// hi - mp_hi (mod P) for hi, mp_hi < P: the tail of every Montgomery reduction here
+ZK_HD uint32_t mont_tail(uint32_t hi, uint32_t mp_hi) {
+#if ZK_MONT_VARIANT == 4
+    return hi - mp_hi + p_if_less(hi, mp_hi);
+#else
+    uint32_t r;
+    return __builtin_sub_overflow(hi, mp_hi, &r) ? r + P : r;
+#endif
+}
 ZK_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
     uint64_t t = (uint64_t)a * b;
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo + (lo << 30);                           // lo * P_INV mod 2^32
-    uint32_t mp_hi = mul_hi_u32(m, P);                      // low words of t and m*P are equal
-    uint32_t r;
-    return __builtin_sub_overflow(hi, mp_hi, &r) ? r + P : r;
+#if ZK_MONT_VARIANT == 0
+    uint32_t mp_hi = (uint32_t)(((uint64_t)m * P) >> 32);   // low words of t and m*P are equal
+    uint32_t r = hi - mp_hi;
+    return hi < mp_hi ? r + P : r;
+#else
+    return mont_tail(hi, mul_hi_u32(m, P));
+#endif
 }
 
 // Host-side helpers (setup, verifier, scalar API).  Plain residues in and out.

@@ -81,9 +81,7 @@ ZK_HD uint32_t mont_mul_add(uint32_t a, uint32_t b, uint64_t c) {
     uint64_t t = (uint64_t)a * b + c;
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo + (lo << 30);
-    uint32_t mp_hi = mul_hi_u32(m, P);
-    uint32_t r;
-    return __builtin_sub_overflow(hi, mp_hi, &r) ? r + P : r;
+    return mont_tail(hi, mul_hi_u32(m, P));
 }
 // v < 2^36 (a sum of 16 residues) -> v mod P.  q' = floor((v >> 30) / 3) is floor(v / P) or one more (P = 3 * 2^30 + 1),
 // so v - q' P lies in [-P, P): one conditional correction on the 64-bit borrow.

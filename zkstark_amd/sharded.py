@@ -759,3 +759,46 @@ def staged_transport(group=None):
             return 1
 
     return _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(all_to_all), _lib.ALL_GATHER_FN(all_gather))
+
+
+def device_transport(group):
+    """A zk_shard_transport over a torch.distributed process group with DEVICE collectives (backend "nccl" = RCCL on ROCm):
+    the library's device pointers are wrapped as tensors (no copy) and exchanged with torch's own RCCL communicator, on
+    the library's stream.  bench.py uses it when the built-in transport (RCCL loaded by the library itself) cannot be
+    set up on a multi-GPU node: a second, independent way to the same wire.  Keep the returned object alive as long as
+    the zk_shard that uses it."""
+    import traceback
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+
+    class _Raw:                                            # __cuda_array_interface__ view of a raw device pointer
+        def __init__(self, ptr, words):
+            self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+    def view(ptr, words):
+        return torch.as_tensor(_Raw(ptr, words), device=torch.device("cuda", torch.cuda.current_device()))
+
+    def all_to_all(user, send, recv, words, stream):
+        try:
+            ext = torch.cuda.ExternalStream(int(stream))
+            with torch.cuda.stream(ext):                   # ordered after the producer of the send pieces, before the hashing
+                outs = [view(recv[q], words) for q in range(world)]
+                ins = [view(send[p], words) for p in range(world)]
+                dist.all_to_all(outs, ins, group=group)
+            return 0
+        except Exception:                                  # a ctypes callback must not raise
+            traceback.print_exc()
+            return 1
+
+    def all_gather(user, send, recv, words, stream):
+        try:
+            ext = torch.cuda.ExternalStream(int(stream))
+            with torch.cuda.stream(ext):
+                dist.all_gather_into_tensor(view(recv, words * world), view(send, words), group=group)
+            return 0
+        except Exception:
+            traceback.print_exc()
+            return 1
+
+    return _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(all_to_all), _lib.ALL_GATHER_FN(all_gather))
