@@ -253,19 +253,62 @@ def main():
         lg = world.bit_length() - 1
         # weak scaling: per-GPU work equals the single-GPU workload; strong: the single-GPU domain over all GPUs
         log_n = args.log_n + (lg if args.scaling == "weak" else 0)
-        uid = [zk.shard_unique_id() if (rank == 0 and not staged) else None]
-        if staged:
-            uid = [os.urandom(128) if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        transport = None
-        if staged:
-            from zkstark_amd import sharded
-            transport = sharded.staged_transport()
-        sp = zk.ShardContext(log_n, log_b, rank, world, uid[0], device=local_rank, transport=transport,
-                             force_collectives=force_sharded, no_root_board=args.plain_collectives)
+        from zkstark_amd import sharded
         trace = zk.trace_fibsq((1 << log_n) - 1)
-        sp.trace_upload(trace)
-        for _ in range(max(args.warmup, 1)):
+
+        def all_ok(ok):                                       # do all ranks agree that a step worked? (gloo, host)
+            t_ = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            return bool(t_.item())
+
+        def make_prover(kind):
+            """kind: 'native' = RCCL loaded by the library (ncclCommInitRank inside zk_shard_create); 'torch' = the same
+            collectives through torch.distributed's own RCCL communicator; 'staged' = host-staged (rehearsal on one GPU)."""
+            if kind == "native":
+                uid_ = [zk.shard_unique_id() if rank == 0 else None]
+                tp_ = None
+            else:
+                uid_ = [os.urandom(128) if rank == 0 else None]    # names the shared-memory root board only
+                tp_ = sharded.staged_transport() if kind == "staged" else sharded.device_transport(dist.new_group(backend="nccl"))
+            dist.broadcast_object_list(uid_, src=0)
+            sp_ = zk.ShardContext(log_n, log_b, rank, world, uid_[0], device=local_rank, transport=tp_,
+                                  force_collectives=force_sharded, no_root_board=args.plain_collectives)
+            sp_.trace_upload(trace)
+            if kind == "native" and os.environ.get("ZK_BENCH_SIMULATE_NATIVE_FAILURE") == "1":   # rehearsal of the fallback
+                sp_.inject_failure()
+                sp_.close()
+                raise zk.ZkError(-2, "simulated failure of the native transport (ZK_BENCH_SIMULATE_NATIVE_FAILURE)")
+            return sp_, tp_, sp_.prove()                       # the first proof is part of "does this transport work"
+
+        kind = "staged" if staged else os.environ.get("ZK_BENCH_TRANSPORT", "native")
+        transport_note = None
+        sp = transport = proof = None
+        err = None
+        try:
+            sp, transport, proof = make_prover(kind)
+        except zk.ZkError as e:
+            err = str(e)
+            print(f"[bench] rank {rank}: {kind} transport failed: {err}", file=sys.stderr, flush=True)
+        if not all_ok(err is None):
+            if kind != "native":
+                sys.exit(5)
+            # The built-in RCCL transport could not be brought up on every rank.  Say so in the record and take the
+            # second, independent way to the same wire: torch.distributed's RCCL communicator (sharded.device_transport).
+            if sp is not None:
+                sp.inject_failure()                           # abort, do not destroy, a communicator that may be half-formed
+                sp.close()
+            sp = transport = proof = None
+            transport_note = f"FALLBACK: native RCCL transport failed ({err or 'on another rank'}); collectives through torch.distributed nccl"
+            kind = "torch"
+            try:
+                sp, transport, proof = make_prover(kind)
+                err = None
+            except zk.ZkError as e:
+                err = str(e)
+                print(f"[bench] rank {rank}: torch transport failed: {err}", file=sys.stderr, flush=True)
+            if not all_ok(err is None):
+                sys.exit(5)
+        for _ in range(max(args.warmup - 1, 0)):
             proof = sp.prove()
         _lib.check(lib.zk_dev_set_profiling(1 << _lib.KERNEL_CLASSES.index("merkle_leaf")))   # dominant kernel only
         dev_stats()
@@ -305,34 +348,43 @@ def main():
             barrier()
             dtl_ = torch.tensor([(time.perf_counter() - t0_) / reps], dtype=torch.float64)
             dist.all_reduce(dtl_, op=dist.ReduceOp.MAX)
-            return float(dtl_.item()), root0 == root1, ctx_.stats()["all_to_all_bytes"]
+            return float(dtl_.item()), root0 == root1, ctx_.stats()["all_to_all_bytes"], root1
         lde_commit = None
         config4 = None
         if not args.no_secondary:                            # BASELINE.json configs[3] shape at the prover's own domain
-            dtl, stable, a2a = time_lde_commit(sp)
+            dtl, stable, a2a, _ = time_lde_commit(sp)
             lde_commit = {"workload": f"configs[3] shape: sharded LDE + all-to-all transpose + Merkle commit, domain 2^{log_n + log_b} over {world} GPUs",
                           "ms": dtl * 1e3, "value": N / dtl, "unit": "field-elements/s", "root_stable": stable,
                           "all_to_all_bytes_per_rank": a2a}
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": st["setup_ms"], "device_bytes": int(st["device_bytes"]),
                   "lde_commit_sharded": lde_commit, "proof_bytes": len(proof.data), "scaling": args.scaling, "units": N * args.steps,
-                  "parallelism": f"one proof sharded over {world} GPUs (cyclic domain; native RCCL all-to-all per commitment)" if not staged
-                                 else f"REHEARSAL: {world} ranks on one GPU, host-staged collectives",
+                  "parallelism": {"native": f"one proof sharded over {world} GPUs (cyclic domain; native RCCL all-to-all per commitment)",
+                                  "torch": f"one proof sharded over {world} GPUs (cyclic domain; RCCL all-to-all per commitment through torch.distributed)",
+                                  "staged": f"REHEARSAL: {world} ranks on one GPU, host-staged collectives"}[kind],
+                  "transport": kind, "transport_note": transport_note,
                   "shard": {**st, "sent_bytes_per_proof_per_rank": st["sent_bytes"], "ranks_agree": same_everywhere,
                             "exchanged_bytes_per_element": st["all_to_all_bytes"] * world / N if world > 1 else 0.0},
                   "parity": parity}
         sp.close()
         if not args.no_secondary and world in (2, 4, 8) and log_b == 3:
             # BASELINE.json configs[3] at EXACTLY its size: domain 2^26 (trace group 2^23) over the N GPUs of this run
-            uid2 = [zk.shard_unique_id() if (rank == 0 and not staged) else (os.urandom(128) if rank == 0 else None)]
+            uid2 = [zk.shard_unique_id() if (rank == 0 and kind == "native") else (os.urandom(128) if rank == 0 else None)]
             dist.broadcast_object_list(uid2, src=0)
             with zk.ShardContext(23, 3, rank, world, uid2[0], device=local_rank, transport=transport,
-                                 no_root_board=args.plain_collectives) as sp4:
+                                 force_collectives=force_sharded, no_root_board=args.plain_collectives) as sp4:
                 sp4.trace_upload(zk.trace_fibsq((1 << 23) - 1))
-                dtl, stable, a2a = time_lde_commit(sp4)
+                dtl, stable, a2a, root4 = time_lde_commit(sp4)
                 st4 = sp4.stats()
+            golden = None
+            try:                                              # tests/golden/config4_2e26.json: the CPU oracle's root (orc.lde + orc.merkle_build)
+                with open(os.path.join(ROOT, "tests", "golden", "config4_2e26.json")) as f:
+                    golden = json.load(f)["pinned"]["f_eval_root"]
+            except (OSError, KeyError, ValueError):
+                pass
             config4 = {"workload": f"configs[3]: domain 2^26 NTT (LDE) sharded over {world} GPUs, all-to-all transpose, Merkle commit",
                        "ms": dtl * 1e3, "value": (1 << 26) / dtl, "unit": "field-elements/s", "root_stable": stable,
-                       "all_to_all_bytes_per_rank": a2a, "rccl_nranks": st4["rccl_nranks"], "chunked_layers": st4["chunked_layers"]}
+                       "all_to_all_bytes_per_rank": a2a, "rccl_nranks": st4["rccl_nranks"], "chunked_layers": st4["chunked_layers"],
+                       "root": root4.hex(), "root_matches_golden": (root4.hex() == golden) if golden else None}
             result["config4_2e26"] = config4
         if parity and parity.get("equal") is False:
             print("[bench] sharded proof differs from the single-GPU prover", file=sys.stderr, flush=True)
@@ -549,7 +601,8 @@ def main():
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],
             "proof_bytes": result["proof_bytes"], "build_hash": _lib.build_hash(),
         }
-        for k in ("device_only", "pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "config4_2e26", "shard"):
+        for k in ("device_only", "pipelined", "soak", "lde_commit_2e20", "reference_size_2e13", "batched_2e13", "lde_commit_sharded", "config4_2e26", "shard",
+                  "transport", "transport_note"):
             if result.get(k) is not None:
                 out[k] = result[k]
         if sharded_run:

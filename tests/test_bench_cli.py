@@ -39,3 +39,42 @@ def test_bench_n2_rehearsal_on_one_gpu():
     assert rec["parity_checked"] is True and rec["shard"]["ranks_agree"] is True
     assert rec["shard"]["sharded_layers"] >= 1 and rec["lde_commit_sharded"]["root_stable"] is True
     assert rec["config"]["domain"] == 1 << 21 and rec["value"] == pytest.approx((1 << 21) / (rec["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_extra,want_transport", [
+    ({"ZK_BENCH_TRANSPORT": "torch"}, "torch"),                      # torch.distributed's RCCL communicator on device pointers
+    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "1"}, "torch"),            # the native transport "fails": the line says so and falls back
+    ({}, "native"),
+])
+def test_bench_sharded_transports_one_rank(env_extra, want_transport):
+    """The N > 1 code path with the one rank a one-GPU box allows (collectives forced): the built-in RCCL transport, the
+    torch.distributed one (sharded.device_transport: the library's device pointers wrapped as tensors, RCCL through
+    torch's communicator on the library's stream), and the recorded fallback from the first to the second."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ZK_BENCH_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "16", "--no-secondary"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert rec["transport"] == want_transport and rec["parity_checked"] is True
+    assert (rec["transport_note"] is not None) == ("ZK_BENCH_SIMULATE_NATIVE_FAILURE" in env_extra)
+    assert rec["shard"]["native_rccl"] == (1 if want_transport == "native" else 0)
+    if want_transport == "native":
+        assert rec["shard"]["rccl_nranks"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_and_exact_config4_rehearsal():
+    """--scaling strong keeps the single-GPU domain; with N in {2, 4, 8} the line also carries BASELINE configs[3] at exactly
+    domain 2^26 (here: two ranks sharing the GPU, host-staged), whose root is the committed golden value."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ZK_BENCH_STAGED"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-n", "17",
+                          "--scaling", "strong"], capture_output=True, text=True, timeout=1100, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert rec["scaling"] == "strong" and rec["config"]["log_n"] == 17 and rec["config"]["domain"] == 1 << 20
+    c4 = rec["config4_2e26"]
+    assert "2^26" in c4["workload"] and c4["root_stable"] is True and c4["root_matches_golden"] is True
+    assert c4["all_to_all_bytes_per_rank"] == 4.0 * (1 << 26) / 2 / 2
