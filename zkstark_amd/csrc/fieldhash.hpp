@@ -151,4 +151,66 @@ ZK_HD Digest fieldhash_inner(const Digest& l, const Digest& r, const FieldHashCo
     return d;
 }
 
+
+#if defined(__HIPCC__)
+// ---- one hash on SIXTEEN lanes -------------------------------------------------------------------------------------
+// The latency-bound levels of a tree (fewer nodes than the chip has lanes) cost one hash LATENCY each, and the serial
+// permutation above is ~9 000 dependent-ish instructions on one lane.  Its state has 16 elements and a DPP row is 16
+// lanes: here lane g of a row holds state element g, the S-boxes of a full round run on 16 lanes at once, the 4x4 block
+// map and the column sums of the external layer are quad broadcasts and row rotations (v_mov_b32 dpp), the sum of the
+// internal layer is four rotate-and-add steps.  ~1 700 instructions per hash: five times less latency, sixteen times
+// the lanes -- exactly what a level with <= 4 096 nodes has to spare.  Same function as fieldhash_inner, bit for bit.
+template <int CTRL>
+__device__ __forceinline__ uint32_t fh_dpp(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+#else
+    return v;                              // host pass of the compiler only parses this
+#endif
+}
+constexpr int kDppRowRor = 0x120;       // row_ror:n = 0x120 + n: lane g reads lane (g + n) mod 16 of its row... (rotate right)
+// E on a row: y = M4 * (own quad), then s = y + (sum of the four quads' y at the same position)
+__device__ __forceinline__ uint32_t fh_external_row(uint32_t s, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    const uint32_t x0 = fh_dpp<0x00>(s), x1 = fh_dpp<0x55>(s), x2 = fh_dpp<0xAA>(s), x3 = fh_dpp<0xFF>(s);   // quad_perm broadcasts
+    const uint64_t acc = (uint64_t)c0 * x0 + (uint64_t)c1 * x1 + (uint64_t)c2 * x2 + (uint64_t)c3 * x3;        // < 16 P
+    const uint32_t y = fh_reduce36(acc);
+    const uint64_t t = (uint64_t)y + y + fh_dpp<kDppRowRor + 4>(y) + fh_dpp<kDppRowRor + 8>(y) + fh_dpp<kDppRowRor + 12>(y);   // < 5 P
+    return fh_reduce36(t);
+}
+// in_word: word g of left || right (canonical), g = lane & 15; returns word g of the digest in lanes g < 8.
+__device__ __forceinline__ uint32_t fieldhash_inner_row16(uint32_t in_word, uint32_t g, const FieldHashConsts& c) {
+    // row (g & 3) of M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] (the add/double sequence of fh_m4 written out)
+    const uint32_t q = g & 3u;
+    const uint32_t c0 = q == 0 ? 5u : q == 1 ? 4u : 1u;
+    const uint32_t c1 = q == 0 ? 7u : q == 1 ? 6u : q == 2 ? 3u : 1u;
+    const uint32_t c2 = q < 2 ? 1u : q == 2 ? 5u : 4u;
+    const uint32_t c3 = q == 0 ? 3u : q == 1 ? 1u : q == 2 ? 7u : 6u;
+    uint32_t s = mont_mul(in_word, R2);
+    const uint32_t keep = s;
+    s = fh_external_row(s, c0, c1, c2, c3);
+#pragma unroll 1
+    for (int r = 0; r < kFhRF / 2; ++r) {
+        s = fh_sbox(add(s, c.rc_full[r][g]));
+        s = fh_external_row(s, c0, c1, c2, c3);
+    }
+    const uint32_t dg = c.diag[g];
+#pragma unroll 1
+    for (int r = 0; r < kFhRP; ++r) {
+        const uint32_t t = fh_sbox(add(s, c.rc_part[r]));
+        s = g == 0 ? t : s;
+        uint32_t sum = add(s, fh_dpp<kDppRowRor + 8>(s));
+        sum = add(sum, fh_dpp<kDppRowRor + 4>(sum));
+        sum = add(sum, fh_dpp<kDppRowRor + 2>(sum));
+        sum = add(sum, fh_dpp<kDppRowRor + 1>(sum));
+        s = mont_mul_add(s, dg, (uint64_t)mont_mul(sum, R2));     // d_g s + sum (d_1 = 1 in Montgomery form: plain s + sum)
+    }
+#pragma unroll 1
+    for (int r = kFhRF / 2; r < kFhRF; ++r) {
+        s = fh_sbox(add(s, c.rc_full[r][g]));
+        s = fh_external_row(s, c0, c1, c2, c3);
+    }
+    return mont_mul(add(s, keep), 1u);
+}
+#endif
+
 }  // namespace zk
