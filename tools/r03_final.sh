@@ -1,0 +1,32 @@
+#!/bin/bash
+# round-3 final GPU session: the artefacts that go into profiles/ (all from ONE build), then the whole parity suite.
+O=gpurun_out/r03f; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --soak-seconds 0 --in-flight 1"
+timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout -k 10 600 python bench.py --hash field --steps 20 --warmup 3 > $O/bench_field.json 2> $O/bench_field.err; echo "bench field rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --soak-seconds 0 --in-flight 1 > $O/prof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_field -- python3 bench.py --hash field --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --soak-seconds 0 --in-flight 1 > $O/prof_field.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_staged -- python3 bench.py --staged-only > $O/prof_staged.log 2>&1
+ZK_HOST_TIMING=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg2 -- python3 tools/config2_only.py 17 20 > $O/prof_cfg2.log 2>&1
+ZK_HOST_TIMING=1 timeout -k 10 120 python tools/config2_only.py 17 20 > $O/config2_laps.txt 2>&1
+for v in "" "ZK_MERKLE_LATENCY_LOG=18" "ZK_MERKLE_LATENCY_LOG=16" "ZK_MERKLE_MAX_K=2" "ZK_MERKLE_MAX_K=2 ZK_MERKLE_LATENCY_LOG=18"; do echo "== ${v:-default}" >> $O/config2_switches.txt; env $v timeout -k 10 120 python tools/config2_only.py 17 200 >> $O/config2_switches.txt 2>&1; done
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_staged -- python3 bench.py --staged-only > $O/pmc_fetch_staged.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_staged -- python3 bench.py --staged-only > $O/pmc_write_staged.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $O/pmc_stall -- $B > $O/pmc_stall.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_staged -- python3 bench.py --staged-only > $O/pmc_sq_staged.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_field -- $B --hash field > $O/pmc_fetch_field.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_field -- $B --hash field > $O/pmc_write_field.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_field -- $B --hash field > $O/pmc_sq_field.log 2>&1
+ZK_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python bench.py --steps 20 --no-secondary > $O/bench_sharded_1rank.json 2> $O/bench_sharded_1rank.err; echo "sharded 1 rank rc=$?"
+ZK_BENCH_FORCE_SHARDED=1 ZK_BENCH_TRANSPORT=torch timeout -k 10 300 python bench.py --steps 20 --no-secondary > $O/bench_sharded_1rank_torch.json 2> $O/bench_sharded_1rank_torch.err; echo "sharded 1 rank torch rc=$?"
+ZK_BENCH_STAGED=1 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --log-n 20 > $O/bench_rehearsal_n2.json 2> $O/bench_rehearsal_n2.err; echo "rehearsal 2 rc=$?"
+ZK_BENCH_STAGED=1 timeout -k 10 400 python bench.py --gpus 4 --steps 3 --warmup 1 --log-n 19 > $O/bench_rehearsal_n4.json 2> $O/bench_rehearsal_n4.err; echo "rehearsal 4 rc=$?"
+ZK_BENCH_STAGED=1 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --scaling strong > $O/bench_rehearsal_n2_strong.json 2> $O/bench_rehearsal_n2_strong.err; echo "rehearsal 2 strong rc=$?"
+for s in "10 3" "14 3" "17 3"; do timeout -k 10 300 python tools/batch_bench.py $s >> $O/batch_sizes.txt 2>&1; done
+find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
+timeout -k 10 1150 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -4 $O/pytest.log
+echo done

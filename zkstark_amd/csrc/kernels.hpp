@@ -26,10 +26,11 @@ enum KernelClass : int {
 constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
 constexpr double kShaInnerOps = 2293.0;
 constexpr double kNttOpsPerElement = 78.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU: 2456-2560 per wave of 32 elements/lane)
-// field-native hash: one permutation per hash.  Dynamic ISA count (tools/kernel_descriptors.py --loops: 4 + 4 trips of the
-// full-round loops, 22 of the partial-round loop, plus the straight-line rest), confirmed by SQ_INSTS_VALU (profiles/)
-constexpr double kFieldLeafOps = 9080.0;
-constexpr double kFieldInnerOps = 9092.0;
+// field-native hash: one permutation per hash.  SQ_INSTS_VALU per wave of the subtree kernel's leaf launch (16 leaf + 15
+// inner hashes) and inner launch (7 inner hashes), solved for the two (profiles/r03_pmc/); the chain probe's loop body is
+// 9 092 by ISA count (tools/kernel_descriptors.py --loops), 9 103 by the counter
+constexpr double kFieldLeafOps = 8895.0;
+constexpr double kFieldInnerOps = 9235.0;
 
 struct Profiler {
     uint32_t mask = 0;
