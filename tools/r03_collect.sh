@@ -1,0 +1,28 @@
+#!/bin/bash
+# Copies the artefacts of tools/r03_final.sh (merged back under gpurun_out/r03f) into profiles/ and derives
+# traffic.json / valu_utilization.json from the PMC passes.  Run in the build container after the GPU call.
+set -e
+cd "$(dirname "$0")/.."
+O=gpurun_out/r03f; P=profiles
+cp $O/bench.json $P/r03_bench_2e24.json; cp $O/bench_field.json $P/r03_bench_2e24_fieldhash.json
+cp $O/bench_sharded_1rank.json $P/r03_bench_sharded_1rank.json; cp $O/bench_sharded_1rank_torch.json $P/r03_bench_sharded_1rank_torch_transport.json
+cp $O/bench_rehearsal_n2.json $P/r03_bench_rehearsal_n2.json; cp $O/bench_rehearsal_n4.json $P/r03_bench_rehearsal_n4.json
+cp $O/bench_rehearsal_n2_strong.json $P/r03_bench_rehearsal_n2_strong.json
+grep -v "amdgpu.ids" $O/batch_sizes.txt > $P/r03_batch_sizes.txt
+grep -v "amdgpu.ids" $O/config2_laps.txt > $P/r03_config2_laps.txt; grep -v "amdgpu.ids" $O/config2_switches.txt > $P/r03_config2_switches.txt
+cp $(find $O/prof_bench -name "*kernel_stats.csv") $P/r03_bench_2e24_kernel_stats.csv
+cp $(find $O/prof_field -name "*kernel_stats.csv") $P/r03_bench_2e24_fieldhash_kernel_stats.csv
+cp $(find $O/prof_staged -name "*kernel_stats.csv") $P/r03_staged_2e24_kernel_stats.csv
+cp $(find $O/prof_cfg2 -name "*kernel_stats.csv") $P/r03_config2_2e20_kernel_stats.csv
+mkdir -p $P/r03_pmc
+for n in fetch write fetch_staged write_staged sq sq_staged stall fetch_field write_field sq_field; do
+    cp $(find $O/pmc_$n -name "*counter_collection.csv") $P/r03_pmc/${n}_counter_collection.csv
+done
+python tools/pmc_traffic.py $O/pmc_fetch,$O/pmc_fetch_staged $O/pmc_write,$O/pmc_write_staged $P/traffic.json "$(git rev-parse --short HEAD)" > /dev/null
+python tools/pmc_traffic.py $O/pmc_fetch_field $O/pmc_write_field $P/r03_traffic_fieldhash.json "$(git rev-parse --short HEAD)" > /dev/null
+python tools/pmc_valu.py $O/pmc_sq $P/valu_utilization.json > /dev/null
+python3 -c "
+import json
+d = json.load(open('$P/traffic.json')); print('traffic.json:', d['commit'], d['build_hash'], round(d['merkle_leaf_bytes_per_launch'] / 1e6, 1), 'MB per leaf launch')
+b = json.load(open('$P/r03_bench_2e24.json')); print('bench:', round(b['ms_per_step'], 3), 'ms per proof, parity_checked', b['parity_checked'], 'build', b['build_hash'])
+f = json.load(open('$P/r03_bench_2e24_fieldhash.json')); print('field:', round(f['ms_per_step'], 2), 'ms per proof, parity_checked', f['parity_checked'], 'build', f['build_hash'])"
