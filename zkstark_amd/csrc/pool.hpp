@@ -15,10 +15,11 @@ namespace zk {
 
 // Minimal fork-join pool: run(n, grain, fn) calls fn(i) for i < n on the workers and the calling thread.
 // Between the rounds of a proof (a few hundred microseconds apart) the workers spin instead of sleeping, so a
-// round's per-proof transcript steps start within a microsecond; after kSpinUs without work they block.
+// round's per-proof transcript steps start within a microsecond; after spin_us without work they block.
 class Pool {
   public:
-    explicit Pool(unsigned workers) {
+    // spin_us: how long an idle worker spins before it blocks (waking a blocked worker costs tens of microseconds)
+    explicit Pool(unsigned workers, double spin_us = 600.0) : spin_us_(spin_us) {
         for (unsigned w = 0; w < workers; ++w) th_.emplace_back([this] { loop(); });
     }
     ~Pool() {
@@ -45,7 +46,7 @@ class Pool {
     }
 
   private:
-    static constexpr double kSpinUs = 600.0;
+    const double spin_us_;
     static double clock_us() {
         return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
@@ -69,7 +70,7 @@ class Pool {
             unsigned spins = 0;
             while (gen_.load(std::memory_order_acquire) == seen) {
                 cpu_relax();
-                if ((++spins & 255) == 0 && clock_us() - t0 > kSpinUs) {
+                if ((++spins & 255) == 0 && clock_us() - t0 > spin_us_) {
                     std::unique_lock<std::mutex> g(m_);
                     cv_.wait(g, [&] { return gen_.load(std::memory_order_acquire) != seen; });
                 }

@@ -130,6 +130,15 @@ int do_lde(zk_ctx* c) {
     return rc;
 }
 
+// Sub-tree of the handed-over digests one host thread reduces alone (ZK_HOST_SUB_LOG, tuning only; default 2^8 digests)
+uint32_t host_sub_log() {
+    static const uint32_t v = [] {
+        const char* e = getenv("ZK_HOST_SUB_LOG");
+        const uint32_t x = e ? (uint32_t)atoi(e) : kHostTopSingle;
+        return (x < 4 || x > kMaxHostLog) ? kHostTopSingle : x;
+    }();
+    return v;
+}
 // How much of tree `tree` the host finishes: the top `host_top` levels of SHA-256 trees larger than that.
 uint32_t top_of(const zk_ctx* c, uint32_t tree) {
     if (c->hash != 0 || !c->host_top) return 0;
@@ -220,8 +229,9 @@ int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
     if (rc) return rc;
     double t0 = now_us();
     memcpy(nodes + 8 * (cnt - 1), c->h_mailbox + kMailDigests, cnt * 32);
-    if (H > kHostTopSingle && c->pool) {
-        const uint32_t top = H - kHostTopSingle;               // 2^top sub-trees of 2^8 digests: ~8 us each, in parallel
+    const uint32_t sub_log = host_sub_log();
+    if (H > sub_log && c->pool) {
+        const uint32_t top = H - sub_log;                      // 2^top sub-trees of 2^sub_log digests (2^8: ~8 us each), in parallel
         c->pool->run((size_t)1 << top, 1, [&](size_t sub) { host_sha_reduce_sub(nodes, H, top, sub); });
         host_sha_reduce(nodes, top);
     } else {
@@ -512,14 +522,19 @@ uint32_t zk_field_order(uint32_t a) {
 uint32_t zk_field_root_of_unity(uint32_t log_order) { return log_order > 30 ? 0 : root_of_unity(log_order); }
 
 static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool tail, zk_ctx** out);
-// the team that reduces hand-over depths above kHostTopSingle (none needed at or below it)
+// the team that reduces hand-over depths above the sub-tree size one thread takes (none needed at or below it)
 static int ctx_team(zk_ctx* c) {
-    const unsigned want = c->host_top > kHostTopSingle ? (1u << (c->host_top - kHostTopSingle)) - 1u : 0u;
+    const uint32_t sub_log = host_sub_log();
+    const unsigned want = c->host_top > sub_log ? (1u << (c->host_top - sub_log)) - 1u : 0u;
     if (c->pool && c->pool->workers() == want) return ZK_OK;
     delete c->pool;
     c->pool = nullptr;
     if (!want) return ZK_OK;
-    c->pool = new (std::nothrow) Pool(want);
+    // the commitments of one big proof are up to 1.6 ms apart (a 2^24-leaf launch): the team spins across them
+    // (ZK_HOST_TEAM_SPIN_US, default 5 ms), or every tree top would pay a futex wake-up
+    double spin_us = 5000.0;
+    if (const char* e = getenv("ZK_HOST_TEAM_SPIN_US")) { const double v = atof(e); if (v > 0) spin_us = v; }
+    c->pool = new (std::nothrow) Pool(want, spin_us);
     return c->pool ? (int)ZK_OK : fail(ZK_ERR_NOMEM, "out of host memory");
 }
 
