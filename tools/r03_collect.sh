@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/r03f; P=profiles
-cp $O/bench.json $P/r03_bench_2e24.json; cp $O/bench_field.json $P/r03_bench_2e24_fieldhash.json
+cp $O/bench_stamped.json $P/r03_bench_2e24.json; cp $O/bench_field.json $P/r03_bench_2e24_fieldhash.json
+cp $O/sha_latency_probe.txt $P/r03_sha_latency_probe.txt; cp $O/montmul_probe.txt $P/r03_montmul_probe.txt
 cp $O/bench_sharded_1rank.json $P/r03_bench_sharded_1rank.json; cp $O/bench_sharded_1rank_torch.json $P/r03_bench_sharded_1rank_torch_transport.json
 cp $O/bench_rehearsal_n2.json $P/r03_bench_rehearsal_n2.json; cp $O/bench_rehearsal_n4.json $P/r03_bench_rehearsal_n4.json
 cp $O/bench_rehearsal_n2_strong.json $P/r03_bench_rehearsal_n2_strong.json
@@ -18,7 +19,7 @@ mkdir -p $P/r03_pmc
 for n in fetch write fetch_staged write_staged sq sq_staged stall fetch_field write_field sq_field; do
     cp $(find $O/pmc_$n -name "*counter_collection.csv") $P/r03_pmc/${n}_counter_collection.csv
 done
-python tools/pmc_traffic.py $O/pmc_fetch,$O/pmc_fetch_staged $O/pmc_write,$O/pmc_write_staged $P/traffic.json "$(git rev-parse --short HEAD)" > /dev/null
+cp $O/traffic.json $P/traffic.json      # made on the GPU box from the same PMC passes (tools/r03_final.sh), stamped there
 python tools/pmc_traffic.py $O/pmc_fetch_field $O/pmc_write_field $P/r03_traffic_fieldhash.json "$(git rev-parse --short HEAD)" > /dev/null
 python tools/pmc_valu.py $O/pmc_sq $P/valu_utilization.json > /dev/null
 python3 -c "

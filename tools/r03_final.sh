@@ -3,6 +3,9 @@
 O=gpurun_out/r03f; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --soak-seconds 0 --in-flight 1"
+timeout -k 10 200 ./tools/sha_latency_probe > $O/sha_latency_probe.txt 2>&1; tail -3 $O/sha_latency_probe.txt
+timeout -k 10 200 ./tools/montmul_probe > $O/montmul_probe.txt 2>&1
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 600 python bench.py --hash field --steps 20 --warmup 3 > $O/bench_field.json 2> $O/bench_field.err; echo "bench field rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --soak-seconds 0 --in-flight 1 > $O/prof_bench.log 2>&1
@@ -21,6 +24,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --outpu
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_field -- $B --hash field > $O/pmc_fetch_field.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_field -- $B --hash field > $O/pmc_write_field.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_field -- $B --hash field > $O/pmc_sq_field.log 2>&1
+# traffic.json from THIS build's PMC passes, then the default line again so that roofline.traffic carries a matching stamp
+python tools/pmc_traffic.py $O/pmc_fetch,$O/pmc_fetch_staged $O/pmc_write,$O/pmc_write_staged profiles/traffic.json "${ZK_COMMIT:-final}" > /dev/null && cp profiles/traffic.json $O/traffic.json
+timeout -k 10 600 python bench.py > $O/bench_stamped.json 2> $O/bench_stamped.err; echo "bench (stamped) rc=$?"
 ZK_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python bench.py --steps 20 --no-secondary > $O/bench_sharded_1rank.json 2> $O/bench_sharded_1rank.err; echo "sharded 1 rank rc=$?"
 ZK_BENCH_FORCE_SHARDED=1 ZK_BENCH_TRANSPORT=torch timeout -k 10 300 python bench.py --steps 20 --no-secondary > $O/bench_sharded_1rank_torch.json 2> $O/bench_sharded_1rank_torch.err; echo "sharded 1 rank torch rc=$?"
 ZK_BENCH_STAGED=1 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --log-n 20 > $O/bench_rehearsal_n2.json 2> $O/bench_rehearsal_n2.err; echo "rehearsal 2 rc=$?"

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import zkstark_amd as zk
 
 t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 60
-count = {"big": 0, "small": 0, "batch": 0, "mid": 0, "sharded": 0}
+count = {"big": 0, "small": 0, "batch": 0, "mid": 0, "sharded": 0, "field": 0, "checked": 0}
 err = []
 
 def loop(name, make, prove):
@@ -20,10 +20,12 @@ def loop(name, make, prove):
     except Exception as e:          # noqa: BLE001
         err.append(f"{name}: {e}")
 
-def mk_ctx(log_n, levels=None):
+def mk_ctx(log_n, levels=None, hash="sha256", checks=False):
     def make():
-        c = zk.Context(log_n, 3, host_levels=levels)
+        c = zk.Context(log_n, 3, host_levels=levels, hash=hash)
         c.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        if checks:
+            c.set_checks(True)
         return c
     return make
 
@@ -42,6 +44,8 @@ th = [threading.Thread(target=loop, args=("sharded", mk_sharded, lambda sp: sp.p
       threading.Thread(target=loop, args=("big", mk_ctx(21), lambda c: c.prove().data)),
       threading.Thread(target=loop, args=("mid", mk_ctx(16, (7, 8)), lambda c: c.prove().data)),
       threading.Thread(target=loop, args=("small", mk_ctx(10), lambda c: c.prove().data)),
+      threading.Thread(target=loop, args=("field", mk_ctx(15, hash="field"), lambda c: c.prove().data)),      # row-of-16 hash in the latency levels
+      threading.Thread(target=loop, args=("checked", mk_ctx(13, checks=True), lambda c: c.prove().data)),     # zk_ctx_set_checks on every proof
       threading.Thread(target=loop, args=("batch", mk_batch, lambda b: b.prove_raw()[0].tobytes()))]
 [t.start() for t in th]
 [t.join() for t in th]
