@@ -164,6 +164,22 @@ def traffic_record():
     return t.get("merkle_leaf_bytes_per_launch"), {k: t.get(k) for k in ("commit", "build_hash", "collected") if k in t}
 
 
+def kernel_clock_record(hash_name):
+    """Clock the dominant kernel held in the PMC pass (GRBM_GUI_ACTIVE over its >= 0.3 ms launches; profiles/valu_utilization.json,
+    stamped like traffic.json): the chain probe's short launches run at a higher clock than a 1.5 ms hashing launch does."""
+    path = os.path.join(ROOT, "profiles", "valu_utilization.json")
+    if hash_name != "sha256" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        v = json.load(f)
+    rows = [k for k in v.get("kernels", []) if "merkle_subtree_kernel<zk::PlainSrc, true, 0>" in k["kernel"] and k.get("clock_ghz")]
+    if not rows:
+        return None
+    k = max(rows, key=lambda r: r["grid_threads"])
+    return {"clock_ghz": k["clock_ghz"], "valu_instr_per_wave": k["valu_instr_per_wave"], "launch_us_under_pmc": k["duration_us"],
+            "stamp": {x: v.get(x) for x in ("commit", "build_hash", "collected")}}
+
+
 def staged_leg(zk, log_n, log_b, device):
     """The stage-by-stage API once (zk_lde, zk_merkle_commit, zk_compose, zk_fri_fold): the stand-alone
     compose_kernel and fri_fold_kernel, which the one-call prover fuses into leaf hashing, timed with HIP events."""
@@ -551,11 +567,17 @@ def main():
         kernel_ns_per_instr = dom["ms"] * 1e6 / (dom["ops"] / 64 / SIMDS) if dom["ops"] else None
         chain = result.get("chain") or []
         best_chain = min((c["ns_per_instr"] for c in chain), default=None)
+        kclk = kernel_clock_record(args.hash) if not sharded_run else None
         valu = {"achieved": valu_ach, "unit": "T lane-ops/s (32-bit)",
                 "peak_mix_weighted": mix_peak, "frac_of_mix_peak": valu_ach / mix_peak,
                 "peak_all_4_cycle": VALU_PEAK_4CYC_TOPS, "frac_of_4_cycle_peak": valu_ach / VALU_PEAK_4CYC_TOPS,
                 "ops_per_leaf_hash": hm["leaf_ops"], "ops_per_inner_hash": hm["inner_ops"], "four_cycle_share": round(hm["four_cycle_share"], 4),
                 "kernel_ns_per_instr": kernel_ns_per_instr,
+                # the same in cycles at the clock the kernel held under the PMC pass: the chain probe's short launches
+                # hold a HIGHER clock (chain[].clock_ghz), so ns compare wall time, cycles compare issue efficiency
+                "kernel_clock_pmc": kclk,
+                "kernel_cycles_per_instr": (kernel_ns_per_instr * kclk["clock_ghz"]) if (kclk and kernel_ns_per_instr) else None,
+                "kernel_clock_from_this_build": bool(kclk) and kclk["stamp"].get("build_hash") == _lib.build_hash(),
                 "chain": chain, "chain_ns_per_instr": best_chain,
                 "frac_of_chain": (best_chain / kernel_ns_per_instr) if (best_chain and kernel_ns_per_instr) else None,
                 "peak_basis": "mix-weighted: 1024 SIMDs x 64 lanes x 2.4 GHz / (4 f4 + 2 (1 - f4)) cycles, f4 = share of 4-cycle ops in the hash "

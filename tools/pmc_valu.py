@@ -33,7 +33,16 @@ def main():
         key = (r["Kernel_Name"], r["Grid_Size"])
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[key]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    res = {"_method": __doc__.strip(), "kernels": []}
+    import os, subprocess, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    commit = sys.argv[3] if len(sys.argv) > 3 else (subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None)
+    sys.path.insert(0, root)
+    try:
+        from zkstark_amd import build as zbuild
+        build_hash = zbuild.source_hash()
+    except Exception:                      # noqa: BLE001
+        build_hash = None
+    res = {"_method": __doc__.strip(), "commit": commit, "build_hash": build_hash, "collected": time.strftime("%Y-%m-%d"), "kernels": []}
     for (name, grid), v in sorted(agg.items(), key=lambda kv: -max(kv[1]["_dur_ns"])):
         if ("merkle" not in name and "ntt" not in name and "coef_prepare" not in name and "compose" not in name and "fri_fold" not in name) \
                 or "SQ_INSTS_VALU" not in v:

@@ -11,13 +11,14 @@ cp $O/bench_rehearsal_n2.json $P/r03_bench_rehearsal_n2.json; cp $O/bench_rehear
 cp $O/bench_rehearsal_n2_strong.json $P/r03_bench_rehearsal_n2_strong.json
 grep -v "amdgpu.ids" $O/batch_sizes.txt > $P/r03_batch_sizes.txt
 grep -v "amdgpu.ids" $O/config2_laps.txt > $P/r03_config2_laps.txt; grep -v "amdgpu.ids" $O/config2_switches.txt > $P/r03_config2_switches.txt
-cp $(find $O/prof_bench -name "*kernel_stats.csv") $P/r03_bench_2e24_kernel_stats.csv
-cp $(find $O/prof_field -name "*kernel_stats.csv") $P/r03_bench_2e24_fieldhash_kernel_stats.csv
-cp $(find $O/prof_staged -name "*kernel_stats.csv") $P/r03_staged_2e24_kernel_stats.csv
-cp $(find $O/prof_cfg2 -name "*kernel_stats.csv") $P/r03_config2_2e20_kernel_stats.csv
+biggest() { ls -S $(find $1 -name "$2") | head -1; }      # a run may leave one file per process: the benchmark's is the large one
+cp $(biggest $O/prof_bench "*kernel_stats.csv") $P/r03_bench_2e24_kernel_stats.csv
+cp $(biggest $O/prof_field "*kernel_stats.csv") $P/r03_bench_2e24_fieldhash_kernel_stats.csv
+cp $(biggest $O/prof_staged "*kernel_stats.csv") $P/r03_staged_2e24_kernel_stats.csv
+cp $(biggest $O/prof_cfg2 "*kernel_stats.csv") $P/r03_config2_2e20_kernel_stats.csv
 mkdir -p $P/r03_pmc
 for n in fetch write fetch_staged write_staged sq sq_staged stall fetch_field write_field sq_field; do
-    cp $(find $O/pmc_$n -name "*counter_collection.csv") $P/r03_pmc/${n}_counter_collection.csv
+    cp $(biggest $O/pmc_$n "*counter_collection.csv") $P/r03_pmc/${n}_counter_collection.csv
 done
 cp $O/traffic.json $P/traffic.json      # made on the GPU box from the same PMC passes (tools/r03_final.sh), stamped there
 python tools/pmc_traffic.py $O/pmc_fetch_field $O/pmc_write_field $P/r03_traffic_fieldhash.json "$(git rev-parse --short HEAD)" > /dev/null
