@@ -66,7 +66,7 @@ def parse():
                     help="skip the secondary figures (configs[1], proofs in flight, batches, staged stages): profiling runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="also report throughput with this many proofs in flight (1 = skip)")
-    ap.add_argument("--soak-seconds", type=float, default=3.0,
+    ap.add_argument("--soak-seconds", type=float, default=5.0,
                     help="after the timed region: keep proving for this long (untimed by the metric; steady-state figure)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=None, help="oracle sample: domain 2^(this+blowup); default: the benchmark's own size")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
