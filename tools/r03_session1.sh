@@ -1,5 +1,7 @@
 #!/bin/bash
-# round-3 GPU session 1: probes, parity of the new subtree kernel, A/B of its switches, configs[4] (field hash) on the record
+# round-3 GPU session 1 (ran at commit f4c0d91, when the subtree kernel still had its heap variant: ZK_MERKLE_HEAP and
+# ZK_MERKLE_WG_WAVES no longer exist, see profiles/r03_ab_subtree_heap.txt): probes, parity of the new subtree kernel,
+# A/B of its switches, configs[4] (field hash) on the record
 O=gpurun_out/r03a; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout -k 10 200 ./tools/montmul_probe > $O/montmul_probe.txt 2>&1; echo "montmul rc=$?"; head -12 $O/montmul_probe.txt
