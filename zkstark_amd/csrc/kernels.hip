@@ -757,7 +757,7 @@ static uint32_t merkle_latency_log() { static const uint32_t v = env_u32("ZK_MER
 template <class SRC>
 static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof,
                                  const MailArgs& mail_in, int hash, uint32_t log_sub = 0xffffffffu, size_t chunk = 0,
-                                 bool leaf_mode = true, bool throughput_only = false) {
+                                 bool leaf_mode = true, uint32_t tp_floor = 0) {
     if (hash) {
         hipError_t e = ensure_fieldhash_consts();
         if (e != hipSuccess) return e;
@@ -771,9 +771,10 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
     auto first_bytes = [&](double b) { return leaf ? b - 4.0 * (double)((size_t)1 << log_sub) + src_bytes : b; };
     const uint32_t kMerkleLatencyLog = merkle_latency_log();
     auto off_at = [&](uint32_t d) { return (size_t)chunk << (d - stop); };   // chunk's first node at depth d
-    // a chunk build (throughput_only) runs the subtree kernels down to the ABSOLUTE depth at which the
-    // whole tree enters its latency phase and stops there; launch_merkle_finish runs that phase once
-    const uint32_t floor_depth = throughput_only ? kMerkleLatencyLog : stop + kMerkleLatencyLog;
+    // a chunk build (tp_floor != 0) runs the subtree kernels down to that ABSOLUTE depth and stops there;
+    // launch_merkle_finish builds everything above it once, for the whole tree
+    const bool throughput_only = tp_floor != 0;
+    const uint32_t floor_depth = throughput_only ? tp_floor : stop + kMerkleLatencyLog;
     while (depth > floor_depth) {
         uint32_t k = depth - floor_depth;
         if (k > merkle_max_k()) k = merkle_max_k();
@@ -832,22 +833,27 @@ hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_pa
 }
 // One chunk (1 / 2^log_chunks of the leaves, still in all-to-all order in its own receive buffer) of a
 // tree over 2^log_m leaves: levels up to the chunk root.  launch_merkle_finish joins the chunk roots.
-// Depth at which chunk builds hand over to launch_merkle_finish: the latency switch of the whole tree when
-// the chunks are large enough for the subtree kernels to end there (>= 256 lanes), else the chunk roots.
+// Depth at which chunk builds hand over to launch_merkle_finish.  A chunk build is ONE leaf launch (the leaves of the
+// chunk and k <= 4 levels, straight from its receive buffer: that is the part worth overlapping with the exchange of the
+// next chunk); everything above -- further throughput launches and the latency phase -- runs once over the whole tree,
+// at full width.  (Round 2 let every chunk run its own inner launches down to the latency switch: four quarter-width
+// launches per level group, each a quarter-filled chip.)  Trees too small for that hand over at the chunk roots.
 static uint32_t chunk_handover_depth(uint32_t log_m, uint32_t log_chunks) {
     const uint32_t lat = merkle_latency_log();
-    return (log_m > lat && lat >= log_chunks + 8) ? lat : log_chunks;
+    if (!(log_m > lat && lat >= log_chunks + 8)) return log_chunks;
+    const uint32_t k = log_m - lat < merkle_max_k() ? log_m - lat : merkle_max_k();
+    return log_m - k;
 }
 uint32_t merkle_finish_start_depth(uint32_t log_m, uint32_t log_chunks) { return chunk_handover_depth(log_m, log_chunks); }
 hipError_t launch_merkle_build_chunk(const uint32_t* recv, uint32_t log_parts, uint32_t log_cnt, uint32_t* nodes, uint32_t log_m,
                                      uint32_t chunk, hipStream_t s, Profiler* prof, int hash) {
     uint32_t log_sub = log_parts + log_cnt;
-    bool tp_only = chunk_handover_depth(log_m, log_m - log_sub) != log_m - log_sub;
+    const uint32_t h = chunk_handover_depth(log_m, log_m - log_sub);
     return merkle_build_t(InterleaveSrc{recv, log_parts, log_cnt}, 4.0 * (double)((size_t)1 << log_sub), log_m, nodes, s, prof, MailArgs{}, hash,
-                          log_sub, chunk, true, tp_only);
+                          log_sub, chunk, true, h != log_m - log_sub ? h : 0u);
 }
-// After every chunk of a 2^log_m-leaf tree (2^log_chunks chunks) has been built down to the switch depth:
-// the latency phase of the whole tree, once.
+// After every chunk of a 2^log_m-leaf tree (2^log_chunks chunks) has been built down to the hand-over depth:
+// the remaining throughput levels and the latency phase of the whole tree, once.
 hipError_t launch_merkle_finish(uint32_t* nodes, uint32_t log_m, uint32_t log_chunks, hipStream_t s, Profiler* prof, int hash,
                                 const MailArgs& mail) {
     const uint32_t start = chunk_handover_depth(log_m, log_chunks);   // depth the chunk builds stopped at
