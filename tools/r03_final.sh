@@ -26,6 +26,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_field -- $B --hash field > $O/pmc_sq_field.log 2>&1
 # traffic.json from THIS build's PMC passes, then the default line again so that roofline.traffic carries a matching stamp
 python tools/pmc_traffic.py $O/pmc_fetch,$O/pmc_fetch_staged $O/pmc_write,$O/pmc_write_staged profiles/traffic.json "${ZK_COMMIT:-final}" > /dev/null && cp profiles/traffic.json $O/traffic.json
+python tools/pmc_valu.py $O/pmc_sq profiles/valu_utilization.json "${ZK_COMMIT:-final}" > /dev/null && cp profiles/valu_utilization.json $O/valu_utilization.json
 timeout -k 10 600 python bench.py > $O/bench_stamped.json 2> $O/bench_stamped.err; echo "bench (stamped) rc=$?"
 ZK_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python bench.py --steps 20 --no-secondary > $O/bench_sharded_1rank.json 2> $O/bench_sharded_1rank.err; echo "sharded 1 rank rc=$?"
 ZK_BENCH_FORCE_SHARDED=1 ZK_BENCH_TRANSPORT=torch timeout -k 10 300 python bench.py --steps 20 --no-secondary > $O/bench_sharded_1rank_torch.json 2> $O/bench_sharded_1rank_torch.err; echo "sharded 1 rank torch rc=$?"
