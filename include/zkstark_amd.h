@@ -107,10 +107,6 @@ int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
  * identical for every setting. */
 int zk_ctx_set_host_levels(zk_ctx *ctx, uint32_t top_log, uint32_t tail_log);
 int zk_ctx_get_host_levels(const zk_ctx *ctx, uint32_t *top_log, uint32_t *tail_log);
-/* Extra host threads (0..63, default 0) that help the calling thread with the FRI tail: with tail_log = 11..13 the layers the
- * host folds and commits are large enough to share (sub-trees of 256 leaves each).  The threads spin while a proof is in
- * progress; outputs are identical for every setting. */
-int zk_ctx_set_host_team(zk_ctx *ctx, uint32_t threads);
 /* The HIP stream every stage is enqueued on (hipStream_t). */
 void *zk_ctx_stream(zk_ctx *ctx);
 

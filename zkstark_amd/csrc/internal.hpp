@@ -32,10 +32,9 @@ const char* last_error();
 
 constexpr uint32_t kMaxQueries = 64;
 constexpr uint32_t kHostTopSingle = 8;                       // hand-over depth one thread reduces alone (255 nodes, ~8 us)
-constexpr uint32_t kMaxHostLog = 10;                         // host_top, log_batch <= 10
-constexpr uint32_t kMaxHostTailLog = 13;                     // host_tail <= 13 (layers that large want a host team, zk_ctx_set_host_team)
+constexpr uint32_t kMaxHostLog = 10;                         // host_top, host_tail, log_batch <= 10
 constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // after the digests of depth host_top
-constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostTailLog); // values of the layer that feeds the host tail
+constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail
 constexpr uint32_t kMaxRadixLog = 8;
 // up to this trace size the coefficient preparation is fused into the first LDE pass (each coefficient is then
 // prepared by the B columns that load it: B-fold redundant arithmetic, one launch and one sweep less)

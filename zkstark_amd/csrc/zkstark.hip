@@ -64,7 +64,6 @@ struct zk_ctx {
     // hand-over depths above kHostTopSingle are reduced by a small team: 2^(host_top - 8) sub-trees of 256 digests, one
     // per thread (workers spin between the commitments of a proof), then the calling thread hashes the levels above
     Pool* pool = nullptr;
-    uint32_t host_team = 0;             // extra host threads for the FRI tail (zk_ctx_set_host_team); 0 = the calling thread alone
     uint32_t* h_stage = nullptr;        // pinned, device-mapped: host-built nodes / values waiting for scatter_kernel
     uint32_t* d_stage = nullptr;
     size_t stage_words = 0, stage_used = 0;
@@ -258,32 +257,16 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     const zk_dom* d = c->dom;
     const uint32_t inv2 = invmod(2);
     const uint32_t cc_m = to_mont(mulmod(mulmod(beta_raw % P, invmod(powmod(d->shift, (uint64_t)1 << round))), inv2));   // beta / (2 w^(2^r))
-    const uint32_t step = powmod(invmod(d->h), (uint64_t)1 << round);                                                   // h^(-2^r)
-    const uint32_t step_m = to_mont(step);
+    const uint32_t step_m = to_mont(powmod(invmod(d->h), (uint64_t)1 << round));                                        // h^(-2^r)
     const uint32_t* in = c->tail_vals.data();
-    // one piece of the layer: fold (the formula of fold_at) and leaf hashes for outputs [b, e)
-    auto piece = [&](size_t b, size_t e) {
-        uint32_t xinv_m = to_mont(powmod(step, (uint64_t)b));   // Montgomery form, like the device tables: canonical * Montgomery = canonical
-        for (size_t i = b; i < e; ++i) {
-            uint32_t u = in[i], v = in[i + half];
-            vals[i] = add(mont_mul(add(u, v), d->inv2_mont), mont_mul(mont_mul(sub(u, v), xinv_m), cc_m));
-            xinv_m = mont_mul(xinv_m, step_m);
-            host_sha_leaf(vals[i], nodes + 8 * (half - 1 + i));
-        }
-    };
-    const uint32_t sub_log = 8;                                  // a thread's share: 256 leaves and the 255 nodes above them (~13 us)
-    if (c->pool && c->host_team && log_out > sub_log) {
-        // a team of host threads (zk_ctx_set_host_team): one sub-tree of 2^8 leaves each, then the levels above on this thread
-        const uint32_t top = log_out - sub_log;
-        c->pool->run((size_t)1 << top, 1, [&](size_t sb) {
-            piece(sb << sub_log, (sb + 1) << sub_log);
-            host_sha_reduce_sub(nodes, log_out, top, sb);
-        });
-        host_sha_reduce(nodes, top);
-    } else {
-        piece(0, half);
-        host_sha_reduce(nodes, log_out);
+    uint32_t xinv_m = to_mont(1);                         // Montgomery form, like the device tables: canonical * Montgomery = canonical
+    for (size_t i = 0; i < half; ++i) {
+        uint32_t u = in[i], v = in[i + half];
+        vals[i] = add(mont_mul(add(u, v), d->inv2_mont), mont_mul(mont_mul(sub(u, v), xinv_m), cc_m));
+        xinv_m = mont_mul(xinv_m, step_m);
     }
+    for (size_t i = 0; i < half; ++i) host_sha_leaf(vals[i], nodes + 8 * (half - 1 + i));
+    host_sha_reduce(nodes, log_out);
     digest_words_to_bytes(nodes, root);
     c->tail_vals.assign(vals, vals + half);
     c->tail_log = log_out;
@@ -297,10 +280,6 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
 int fri_round_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[32]) {
     if (c->tail_have && c->tail_log == c->L - round && c->L - round - 1 <= c->host_tail) return host_fold_commit(c, round, beta_raw, root);
     int rc = do_fold_commit(c, round, beta_raw);
-    // the team has been idle for the whole proof and may have gone to sleep: wake it while the device works on one of the
-    // last layers it commits itself (a futex wake-up costs tens of microseconds; the workers then spin into the tail)
-    if (!rc && c->pool && c->host_team && c->host_tail && c->L - round - 1 <= c->host_tail + 2 && c->L - round - 1 > c->host_tail)
-        c->pool->run(c->pool->workers() + 1, 1, [](size_t) {});
     return rc ? rc : read_commit(c, 2 + round, root);
 }
 void begin_proof(zk_ctx* c) {
@@ -394,11 +373,8 @@ int check_degree(zk_ctx* c, uint32_t layer, uint32_t want_deg, const char* cite)
         }
         return ZK_OK;
     }
-    int rc;
-    // a layer the host tail built is still on the host side: bring the staged pieces into the device arrays first
-    if (c->tail_have && c->tail_log == lg && layer >= 2 && (rc = flush_host_parts(c))) return rc;
     const Plan pl = make_plan(lg);
-    rc = run_dif(src, c->d_check, lg, pl, c->dom->Hinv.view(), c->dom->L, 0, c->stream);
+    int rc = run_dif(src, c->d_check, lg, pl, c->dom->Hinv.view(), c->dom->L, 0, c->stream);
     if (rc) return rc;
     uint32_t* res = c->d_check + c->N;
     HIPCHK(hipMemsetAsync(res, 0, 8, c->stream));
@@ -549,8 +525,7 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
 // the team that reduces hand-over depths above the sub-tree size one thread takes (none needed at or below it)
 static int ctx_team(zk_ctx* c) {
     const uint32_t sub_log = host_sub_log();
-    unsigned want = c->host_top > sub_log ? (1u << (c->host_top - sub_log)) - 1u : 0u;
-    if (c->host_team > want) want = c->host_team;              // the FRI tail's team (zk_ctx_set_host_team)
+    const unsigned want = c->host_top > sub_log ? (1u << (c->host_top - sub_log)) - 1u : 0u;
     if (c->pool && c->pool->workers() == want) return ZK_OK;
     delete c->pool;
     c->pool = nullptr;
@@ -625,7 +600,7 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     memset(c->h_mailbox, 0, mail_bytes);
     HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_mailbox, 0));
     // staging for host-built tree tops and tail layers: one top per tree, the tail layers and their trees, the segment table
-    c->stage_words = (size_t)(c->R + 2) * ((size_t)16 << kMaxHostLog) + ((size_t)40 << kMaxHostTailLog);   // tree tops + the tail's layers and trees
+    c->stage_words = (size_t)(c->R + 2) * ((size_t)16 << kMaxHostLog) + ((size_t)64 << kMaxHostLog);
     const size_t seg_bytes = 4 * 34 * sizeof(ScatterSeg);
     HIPCHK_C(hipHostMalloc((void**)&c->h_stage, c->stage_words * 4 + seg_bytes, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_stage, c->h_stage, 0));
@@ -635,8 +610,7 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
         c->host_top = 8;
         c->host_tail = 9;
         if (const char* e = getenv("ZK_HOST_TOP_LOG")) c->host_top = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 8;
-        if (const char* e = getenv("ZK_HOST_TAIL_LOG")) c->host_tail = (uint32_t)atoi(e) <= kMaxHostTailLog ? (uint32_t)atoi(e) : 9;
-        if (const char* e = getenv("ZK_HOST_TEAM")) c->host_team = (uint32_t)atoi(e) <= 63 ? (uint32_t)atoi(e) : 0;
+        if (const char* e = getenv("ZK_HOST_TAIL_LOG")) c->host_tail = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 9;
         if (!c->host_top) c->host_tail = 0;
     }
     if (int prc = ctx_team(c)) { zk_ctx_destroy(c); return prc; }
@@ -691,18 +665,10 @@ int zk_ctx_set_queries(zk_ctx* c, uint32_t n_queries) {
 
 int zk_ctx_set_host_levels(zk_ctx* c, uint32_t top_log, uint32_t tail_log) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
-    if (top_log > kMaxHostLog || tail_log > kMaxHostTailLog || (tail_log && !top_log))
-        return fail(ZK_ERR_INVALID, "zk_ctx_set_host_levels: need top_log <= %u, tail_log <= %u, and top_log > 0 when tail_log > 0", kMaxHostLog, kMaxHostTailLog);
+    if (top_log > kMaxHostLog || tail_log > kMaxHostLog || (tail_log && !top_log))
+        return fail(ZK_ERR_INVALID, "zk_ctx_set_host_levels: need top_log, tail_log <= %u, and top_log > 0 when tail_log > 0", kMaxHostLog);
     c->host_top = top_log;
     c->host_tail = tail_log;
-    return ctx_team(c);
-}
-// Extra host threads for the FRI tail (layers of <= 2^tail_log values are folded and committed on the host): each takes
-// sub-trees of 256 leaves.  0 (default) = the calling thread alone, which is right for tail_log <= 9 or 10.
-int zk_ctx_set_host_team(zk_ctx* c, uint32_t threads) {
-    if (!c) return fail(ZK_ERR_INVALID, "null context");
-    if (threads > 63) return fail(ZK_ERR_INVALID, "zk_ctx_set_host_team: at most 63 extra threads");
-    c->host_team = threads;
     return ctx_team(c);
 }
 int zk_ctx_get_host_levels(const zk_ctx* c, uint32_t* top_log, uint32_t* tail_log) {

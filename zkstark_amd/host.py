@@ -318,10 +318,6 @@ class Context:
     def set_host_levels(self, top_log, tail_log):
         check(_lib.load().zk_ctx_set_host_levels(self._h, top_log, tail_log))
 
-    def set_host_team(self, threads):
-        """Extra host threads for the FRI tail (zk_ctx_set_host_team)."""
-        check(_lib.load().zk_ctx_set_host_team(self._h, threads))
-
     def set_checks(self, on=True):
         """The reference's in-prover assertions (prover.rs:64-66, :148-159/:169, :228-251) inside prove()."""
         check(_lib.load().zk_ctx_set_checks(self._h, int(on)))
