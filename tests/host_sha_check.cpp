@@ -1,5 +1,6 @@
 // Prints digests from csrc/host_sha.cpp for tests/test_host_sha.py (compared there with hashlib).
-//   host_sha_check <ext:0|1> <depth> <seed>
+//   host_sha_check <ext: 0 portable | 1 SHA extensions, one or two nodes at a time | 2 + sixteen at a time (AVX-512F)> <depth> <seed>
+// prints "<sha extensions in use> <wide path in use>", the heap, the chain
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -13,16 +14,19 @@ static void hex(const uint32_t w[8]) {
 int main(int argc, char** argv) {
     if (argc != 4) return 2;
     zk::host_sha_use_extensions(atoi(argv[1]) != 0);
-    printf("%d\n", zk::host_sha_available() ? 1 : 0);
+    zk::host_sha_use_wide(atoi(argv[1]) == 2);
+    printf("%d %d\n", zk::host_sha_available() ? 1 : 0, zk::host_sha_wide_available() ? 1 : 0);
     const uint32_t depth = (uint32_t)atoi(argv[2]);
     uint32_t x = (uint32_t)strtoul(argv[3], nullptr, 10);
     const size_t m = (size_t)1 << depth;
     std::vector<uint32_t> nodes(8 * (2 * m - 1));
+    std::vector<uint32_t> vals(m);
     for (size_t i = 0; i < m; ++i) {                     // leaves from an LCG; the first few values are edge cases
         x = x * 1664525u + 1013904223u;
-        uint32_t v = i == 0 ? 0u : i == 1 ? 0xffffffffu : i == 2 ? 3221225472u : x;
-        zk::host_sha_leaf(v, &nodes[8 * (m - 1 + i)]);
+        vals[i] = i == 0 ? 0u : i == 1 ? 0xffffffffu : i == 2 ? 3221225472u : x;
     }
+    zk::host_sha_leaves(vals.data(), m, &nodes[8 * (m - 1)]);
+    if (m > 2) zk::host_sha_leaf(vals[2], &nodes[8 * (m - 1 + 2)]);      // the one-leaf entry point too
     zk::host_sha_reduce(nodes.data(), depth);
     for (size_t i = 0; i < 2 * m - 1; ++i) hex(&nodes[8 * i]);
     // transcript-style compression chain: state <- compress(state, block) over three blocks

@@ -1,5 +1,6 @@
 """csrc/host_sha.cpp (the host thread's share of the Merkle trees: tops and small FRI layers, plus the
-transcript compressions) against hashlib, through both code paths: x86 SHA extensions and portable."""
+transcript compressions) against hashlib, through every code path: portable, x86 SHA extensions (one or two nodes at a
+time), and sixteen nodes at a time on AVX-512 registers for levels that wide."""
 import hashlib
 import os
 import struct
@@ -37,14 +38,16 @@ def _expected(depth, seed):
     return [n.hex() for n in nodes], hashlib.sha256(msg).hexdigest()
 
 
-@pytest.mark.parametrize("ext", [0, 1])
-@pytest.mark.parametrize("depth,seed", [(0, 1), (1, 2), (3, 7), (8, 12345), (10, 99)])
+@pytest.mark.parametrize("ext", [0, 1, 2])
+@pytest.mark.parametrize("depth,seed", [(0, 1), (1, 2), (3, 7), (4, 5), (5, 3), (8, 12345), (10, 99)])
 def test_host_sha_matches_hashlib(checker, ext, depth, seed):
     out = subprocess.run([checker, str(ext), str(depth), str(seed)], capture_output=True, text=True, check=True).stdout.split()
-    have_ext = out[0] == "1"
+    have_ext, have_wide = out[0] == "1", out[1] == "1"
     if ext and not have_ext:
         pytest.skip("CPU without SHA extensions: only the portable path exists here")
-    assert have_ext == bool(ext)
+    if ext == 2 and not have_wide:
+        pytest.skip("CPU without AVX-512F: no sixteen-at-a-time path here")
+    assert have_ext == bool(ext) and have_wide == (ext == 2)
     nodes, chain = _expected(depth, seed)
-    assert out[1:-1] == nodes
+    assert out[2:-1] == nodes
     assert out[-1] == chain

@@ -7,7 +7,11 @@
 using namespace zk;
 
 int main() {
-    printf("sha extensions: %d\n", host_sha_available());
+    printf("sha extensions: %d, sixteen at a time (AVX-512F): %d\n", host_sha_available(), host_sha_wide_available());
+    const bool have_wide = host_sha_wide_available();
+    for (int wide = have_wide ? 1 : 0; wide >= 0; --wide) {
+    host_sha_use_wide(wide != 0);
+    printf("-- levels of >= 16 nodes %s\n", wide ? "sixteen at a time on 512-bit registers" : "on the SHA unit");
     for (int depth = 5; depth <= 10; ++depth) {
         std::vector<uint32_t> nodes(8 * ((2u << depth) - 1));
         for (size_t i = 0; i < nodes.size(); ++i) nodes[i] = (uint32_t)(i * 2654435761u);
@@ -28,6 +32,13 @@ int main() {
         double us1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
         printf("top of 2^%d nodes: %.2f us (%.1f ns/node); one at a time %.2f us (%.1f ns/node)\n", depth, us,
                us * 1000 / ((1 << depth) - 1), us1, us1 * 1000 / ((1 << depth) - 1));
+    }
+    std::vector<uint32_t> vals(512), out(8 * 512);
+    for (size_t i = 0; i < vals.size(); ++i) vals[i] = (uint32_t)(i * 2654435761u);
+    auto t1 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 2000; ++k) { vals[0] = k; host_sha_leaves(vals.data(), vals.size(), out.data()); }
+    printf("512 leaves: %.2f us (%.1f ns per leaf)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / 2000,
+           std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t1).count() / 2000 / 512);
     }
     uint32_t o[8];
     auto t0 = std::chrono::steady_clock::now();

@@ -108,7 +108,7 @@ const uint32_t* bfinish_roots(zk_batch* b, uint32_t tree, uint32_t log_m) {
         for (uint32_t dd = h; dd-- > 0;) {
             const uint32_t* child = lvl[dd + 1] + ((p << (dd + 1)) * 8);
             uint32_t* out = lvl[dd] + ((p << dd) * 8);
-            for (size_t i = 0; i < ((size_t)1 << dd); ++i) host_sha_inner(child + 16 * i, child + 16 * i + 8, out + 8 * i);
+            host_sha_inner_run(child, out, (size_t)1 << dd);
         }
     });
     for (uint32_t dd = 0; dd < h; ++dd) {

@@ -3,6 +3,7 @@
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace zk {
@@ -24,6 +25,7 @@ const uint32_t IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x51
 // K[t] + W[t] of the second block of a 64-byte message (0x80, zeros, length 512): its schedule is constant
 alignas(16) uint32_t PADKW[64];
 bool g_have_sha = false, g_cpu_has_sha = false;
+bool g_have_x16 = false, g_cpu_has_x16 = false;       // AVX-512F: sixteen nodes per instruction stream (below)
 
 inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
@@ -31,6 +33,8 @@ struct Init {
     Init() {
         __builtin_cpu_init();
         g_cpu_has_sha = g_have_sha = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+        g_cpu_has_x16 = g_have_x16 = g_cpu_has_sha && __builtin_cpu_supports("avx512f");
+        if (const char* e = getenv("ZK_HOST_SHA_WIDE")) g_have_x16 = g_have_x16 && atoi(e) != 0;      // A/B switch
         uint32_t w[64] = {0x80000000u};
         w[15] = 512u;
         for (int t = 16; t < 64; ++t) {
@@ -169,12 +173,113 @@ ZK_SHA_TARGET void leaf_ni(uint32_t v, uint32_t* out) {
     rounds_msg(s0, s1, m);
     store_state(out, s0, s1);
 }
+// ---- sixteen nodes at a time (AVX-512F) ------------------------------------------------------------------------
+// One SHA unit finishes a node in ~31 ns however many chains it is fed (two sha256rnds2 per four rounds, back to back).
+// A level of >= 16 nodes is wide enough for the other way round: the textbook compression on 512-bit registers, one
+// node per 32-bit lane -- vprord for the rotations, vpternlogd for the three-input functions (Ch, Maj, the xor of three
+// rotations), sixteen message words transposed in and eight state words transposed out.  ~2 800 vector instructions
+// per sixteen nodes instead of sixteen times ~140 SHA-unit steps: measured ~12 ns per node (tools/host_sha_bench.cpp).
+#define ZK_X16_TARGET __attribute__((target("avx512f")))
+#define ZK_ROR(x, n) _mm512_ror_epi32((x), (n))
+#define ZK_XOR3(a, b, c) _mm512_ternarylogic_epi32((a), (b), (c), 0x96)
+
+// r[i] lane j  <->  r[j] lane i
+ZK_X16_TARGET inline void transpose16(__m512i r[16]) {
+    __m512i t[16], u[16];
+    for (int i = 0; i < 8; ++i) {
+        t[2 * i] = _mm512_unpacklo_epi32(r[2 * i], r[2 * i + 1]);
+        t[2 * i + 1] = _mm512_unpackhi_epi32(r[2 * i], r[2 * i + 1]);
+    }
+    for (int i = 0; i < 16; i += 4) {
+        u[i] = _mm512_unpacklo_epi64(t[i], t[i + 2]);
+        u[i + 1] = _mm512_unpackhi_epi64(t[i], t[i + 2]);
+        u[i + 2] = _mm512_unpacklo_epi64(t[i + 1], t[i + 3]);
+        u[i + 3] = _mm512_unpackhi_epi64(t[i + 1], t[i + 3]);
+    }
+    // u[4 g + k], 128-bit lane q: column 4 q + k of rows 4 g .. 4 g + 3
+    for (int k = 0; k < 4; ++k) {
+        t[k] = _mm512_shuffle_i32x4(u[k], u[4 + k], 0x88);            // lanes q = 0, 2 of row groups 0, 1
+        t[4 + k] = _mm512_shuffle_i32x4(u[k], u[4 + k], 0xdd);        // lanes q = 1, 3
+        t[8 + k] = _mm512_shuffle_i32x4(u[8 + k], u[12 + k], 0x88);   // row groups 2, 3
+        t[12 + k] = _mm512_shuffle_i32x4(u[8 + k], u[12 + k], 0xdd);
+    }
+    for (int k = 0; k < 4; ++k) {
+        r[k] = _mm512_shuffle_i32x4(t[k], t[8 + k], 0x88);            // q = 0: columns 0..3
+        r[8 + k] = _mm512_shuffle_i32x4(t[k], t[8 + k], 0xdd);        // q = 2: columns 8..11
+        r[4 + k] = _mm512_shuffle_i32x4(t[4 + k], t[12 + k], 0x88);   // q = 1: columns 4..7
+        r[12 + k] = _mm512_shuffle_i32x4(t[4 + k], t[12 + k], 0xdd);  // q = 3: columns 12..15
+    }
+}
+
+// 64 rounds on sixteen independent states; MSG: w[16] is the message (rolling schedule), otherwise the constant padding
+// block of a 64-byte message (K + W from PADKW)
+template <bool MSG>
+ZK_X16_TARGET inline void rounds_x16(__m512i st[8], __m512i w[16]) {
+    __m512i a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma GCC unroll 64
+    for (int t = 0; t < 64; ++t) {
+        __m512i wk;
+        if (MSG) {
+            if (t >= 16) {
+                const __m512i w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+                const __m512i s0 = ZK_XOR3(ZK_ROR(w15, 7), ZK_ROR(w15, 18), _mm512_srli_epi32(w15, 3));
+                const __m512i s1 = ZK_XOR3(ZK_ROR(w2, 17), ZK_ROR(w2, 19), _mm512_srli_epi32(w2, 10));
+                w[t & 15] = _mm512_add_epi32(_mm512_add_epi32(w[t & 15], s0), _mm512_add_epi32(w[(t + 9) & 15], s1));
+            }
+            wk = _mm512_add_epi32(w[t & 15], _mm512_set1_epi32((int)K[t]));
+        } else {
+            wk = _mm512_set1_epi32((int)PADKW[t]);
+        }
+        const __m512i S1 = ZK_XOR3(ZK_ROR(e, 6), ZK_ROR(e, 11), ZK_ROR(e, 25));
+        const __m512i t1 = _mm512_add_epi32(_mm512_add_epi32(h, S1), _mm512_add_epi32(_mm512_ternarylogic_epi32(e, f, g, 0xCA), wk));
+        const __m512i S0 = ZK_XOR3(ZK_ROR(a, 2), ZK_ROR(a, 13), ZK_ROR(a, 22));
+        const __m512i t2 = _mm512_add_epi32(S0, _mm512_ternarylogic_epi32(a, b, c, 0xE8));
+        h = g; g = f; f = e; e = _mm512_add_epi32(d, t1); d = c; c = b; b = a; a = _mm512_add_epi32(t1, t2);
+    }
+    st[0] = _mm512_add_epi32(st[0], a); st[1] = _mm512_add_epi32(st[1], b); st[2] = _mm512_add_epi32(st[2], c); st[3] = _mm512_add_epi32(st[3], d);
+    st[4] = _mm512_add_epi32(st[4], e); st[5] = _mm512_add_epi32(st[5], f); st[6] = _mm512_add_epi32(st[6], g); st[7] = _mm512_add_epi32(st[7], h);
+}
+ZK_X16_TARGET inline void store_x16(const __m512i st[8], uint32_t* out) {       // sixteen digests of eight words
+    __m512i r[16];
+    for (int i = 0; i < 8; ++i) { r[i] = st[i]; r[8 + i] = _mm512_setzero_si512(); }
+    transpose16(r);
+    for (int n = 0; n < 16; ++n) _mm256_storeu_si256((__m256i*)(out + 8 * n), _mm512_castsi512_si256(r[n]));
+}
+// in: 32 digests (the children of sixteen consecutive nodes, contiguous in the heap); out: the sixteen nodes
+ZK_X16_TARGET void inner_x16(const uint32_t* in, uint32_t* out) {
+    __m512i w[16], st[8];
+    for (int n = 0; n < 16; ++n) w[n] = _mm512_loadu_si512((const void*)(in + 16 * n));   // row n = message of node n
+    transpose16(w);                                                                        // row t = word t of every node
+    for (int i = 0; i < 8; ++i) st[i] = _mm512_set1_epi32((int)IV[i]);
+    rounds_x16<true>(st, w);
+    rounds_x16<false>(st, w);
+    store_x16(st, out);
+}
+// sixteen leaves: SHA256(be32(v)) for v = vals[0..15] (merkle.rs:30-34)
+ZK_X16_TARGET void leaves_x16(const uint32_t* vals, uint32_t* out) {
+    __m512i w[16], st[8];
+    w[0] = _mm512_loadu_si512((const void*)vals);
+    w[1] = _mm512_set1_epi32((int)0x80000000u);
+    for (int i = 2; i < 15; ++i) w[i] = _mm512_setzero_si512();
+    w[15] = _mm512_set1_epi32(32);
+    for (int i = 0; i < 8; ++i) st[i] = _mm512_set1_epi32((int)IV[i]);
+    rounds_x16<true>(st, w);
+    store_x16(st, out);
+}
+
+// `cnt` consecutive nodes of one level from their 2 cnt contiguous children
+void inner_run(const uint32_t* child, uint32_t* out, size_t cnt) {
+    size_t i = 0;
+    if (g_have_x16)
+        for (; i + 16 <= cnt; i += 16) inner_x16(child + 16 * i, out + 8 * i);
+    for (; i + 2 <= cnt; i += 2) inner_ni_x2(child + 16 * i, out + 8 * i);
+    for (; i < cnt; ++i) inner_ni(child + 16 * i, child + 16 * i + 8, out + 8 * i);
+}
+
 ZK_SHA_TARGET void reduce_ni(uint32_t* nodes, uint32_t depth) {
     for (uint32_t d = depth; d-- > 0;) {
         const size_t base = ((size_t)1 << d) - 1, child = ((size_t)2 << d) - 1, cnt = (size_t)1 << d;
-        size_t i = 0;
-        for (; i + 2 <= cnt; i += 2) inner_ni_x2(nodes + 8 * (child + 2 * i), nodes + 8 * (base + i));   // children are contiguous
-        for (; i < cnt; ++i) inner_ni(nodes + 8 * (child + 2 * i), nodes + 8 * (child + 2 * i + 1), nodes + 8 * (base + i));
+        inner_run(nodes + 8 * child, nodes + 8 * base, cnt);       // the children of consecutive nodes are contiguous
     }
 }
 
@@ -184,9 +289,7 @@ ZK_SHA_TARGET void reduce_sub_ni(uint32_t* nodes, uint32_t depth, uint32_t top, 
     for (uint32_t d = depth; d-- > top;) {
         const size_t cnt = (size_t)1 << (d - top);
         const size_t base = ((size_t)1 << d) - 1 + sub * cnt, child = ((size_t)2 << d) - 1 + 2 * sub * cnt;
-        size_t i = 0;
-        for (; i + 2 <= cnt; i += 2) inner_ni_x2(nodes + 8 * (child + 2 * i), nodes + 8 * (base + i));
-        for (; i < cnt; ++i) inner_ni(nodes + 8 * (child + 2 * i), nodes + 8 * (child + 2 * i + 1), nodes + 8 * (base + i));
+        inner_run(nodes + 8 * child, nodes + 8 * base, cnt);
     }
 }
 
@@ -211,7 +314,9 @@ void compress_generic(uint32_t st[8], const uint32_t blk[16]) {
 }  // namespace
 
 bool host_sha_available() { return g_have_sha; }
-void host_sha_use_extensions(bool on) { g_have_sha = on && g_cpu_has_sha; }
+void host_sha_use_extensions(bool on) { g_have_sha = on && g_cpu_has_sha; g_have_x16 = on && g_cpu_has_x16; }
+bool host_sha_wide_available() { return g_have_x16; }
+void host_sha_use_wide(bool on) { g_have_x16 = on && g_have_sha && g_cpu_has_x16; }
 
 void host_sha_compress(uint32_t state[8], const uint32_t block[16]) {
     if (g_have_sha) compress_ni(state, block);
@@ -227,6 +332,13 @@ void host_sha_leaf(uint32_t v, uint32_t out[8]) {
     memcpy(out, st, 32);
 }
 
+void host_sha_leaves(const uint32_t* vals, size_t n, uint32_t* out) {
+    size_t i = 0;
+    if (g_have_x16)
+        for (; i + 16 <= n; i += 16) leaves_x16(vals + i, out + 8 * i);
+    for (; i < n; ++i) host_sha_leaf(vals[i], out + 8 * i);
+}
+
 void host_sha_inner(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]) {
     if (g_have_sha) { inner_ni(left, right, out); return; }
     uint32_t blk[16], st[8];
@@ -237,6 +349,11 @@ void host_sha_inner(const uint32_t left[8], const uint32_t right[8], uint32_t ou
     uint32_t pad[16] = {0x80000000u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 512u};
     compress_generic(st, pad);
     memcpy(out, st, 32);
+}
+
+void host_sha_inner_run(const uint32_t* children, uint32_t* out, size_t cnt) {
+    if (g_have_sha) { inner_run(children, out, cnt); return; }
+    for (size_t i = 0; i < cnt; ++i) host_sha_inner(children + 16 * i, children + 16 * i + 8, out + 8 * i);
 }
 
 void host_sha_reduce_sub(uint32_t* nodes, uint32_t depth, uint32_t top, size_t sub) {

@@ -69,6 +69,9 @@ __device__ __forceinline__ QuadLane quad_lane(uint32_t lane) {
     return q;
 }
 
+// (Tried and dropped, tools/sha_quad_probe.hip: the 128 round constants resident in VGPRs -- 7 555 instead of 7 697 cycles per
+// hash, but 260 registers for every kernel that contains this code; preparing h + K + W one round ahead so that no
+// instruction needs the result of the one before it -- slower, the compiler separates split assembly blocks with s_nop.)
 // One round as ONE block of assembly.  The order is the point: a DPP operand must have been written at least two
 // instructions earlier (the hardware does not interlock that, and neither the compiler's hazard recogniser nor its
 // scheduler looks into inline assembly), and on a wave that has its SIMD to itself an s_nop costs about as much as an

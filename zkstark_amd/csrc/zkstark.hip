@@ -265,7 +265,7 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
         vals[i] = add(mont_mul(add(u, v), d->inv2_mont), mont_mul(mont_mul(sub(u, v), xinv_m), cc_m));
         xinv_m = mont_mul(xinv_m, step_m);
     }
-    for (size_t i = 0; i < half; ++i) host_sha_leaf(vals[i], nodes + 8 * (half - 1 + i));
+    host_sha_leaves(vals, half, nodes + 8 * (half - 1));
     host_sha_reduce(nodes, log_out);
     digest_words_to_bytes(nodes, root);
     c->tail_vals.assign(vals, vals + half);
