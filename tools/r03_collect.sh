@@ -6,6 +6,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/r03f; P=profiles
 cp $O/bench_stamped.json $P/r03_bench_2e24.json; cp $O/bench_field.json $P/r03_bench_2e24_fieldhash.json
 cp $O/sha_latency_probe.txt $P/r03_sha_latency_probe.txt; cp $O/montmul_probe.txt $P/r03_montmul_probe.txt
+cp $O/sha_quad_probe.txt $P/r03_sha_quad_probe.txt; cp $O/host_sha.txt $P/r03_host_sha.txt; cp $O/levels_report.txt $P/r03_levels_quad.txt
 cp $O/bench_sharded_1rank.json $P/r03_bench_sharded_1rank.json; cp $O/bench_sharded_1rank_torch.json $P/r03_bench_sharded_1rank_torch_transport.json
 cp $O/bench_rehearsal_n2.json $P/r03_bench_rehearsal_n2.json; cp $O/bench_rehearsal_n4.json $P/r03_bench_rehearsal_n4.json
 cp $O/bench_rehearsal_n2_strong.json $P/r03_bench_rehearsal_n2_strong.json

@@ -5,6 +5,9 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --soak-seconds 0 --in-flight 1"
 timeout -k 10 200 ./tools/sha_latency_probe > $O/sha_latency_probe.txt 2>&1; tail -3 $O/sha_latency_probe.txt
 timeout -k 10 200 ./tools/montmul_probe > $O/montmul_probe.txt 2>&1
+timeout -k 10 100 ./tools/sha_quad_probe > $O/sha_quad_probe.txt 2>&1; tail -3 $O/sha_quad_probe.txt
+timeout -k 10 100 ./tools/host_sha_bench > $O/host_sha.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_levels -- python3 tools/merkle_levels_probe.py > $O/levels.log 2>&1 && python3 tools/merkle_levels_report.py $O/prof_levels > $O/levels_report.txt 2>&1
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 600 python bench.py --hash field --steps 20 --warmup 3 > $O/bench_field.json 2> $O/bench_field.err; echo "bench field rc=$?"
