@@ -450,7 +450,8 @@ def main():
         ctx.set_profiling(())
         result = {"dt": dt, "dom": dom, "per_kernel": per_kernel, "setup_ms": ctx.setup_ms,
                   "device_bytes": ctx.device_bytes, "proof_bytes": len(proof.data), "scaling": "weak",
-                  "units": N * args.steps, "parallelism": "single-gpu", "host_levels": list(ctx.host_levels)}
+                  "units": N * args.steps, "parallelism": "single-gpu", "host_levels": list(ctx.host_levels),
+                  "host_hashing": zk.host_hash_mode()}
         # the same proofs with everything on the device (host_levels (0, 0): no tree tops, no FRI tail on the host thread)
         if args.hash == "sha256" and tuple(ctx.host_levels) != (0, 0):
             keep = tuple(ctx.host_levels)
@@ -635,7 +636,7 @@ def main():
                        "log_n": log_n, "log_blowup": log_b, "domain": 1 << (log_n + log_b), "fri_rounds": log_n, "merkle_hash": args.hash,
                        "parallelism": result["parallelism"],
                        # host thread's share of the latency-bound end: [tree-top levels, log2 of the largest host-side FRI layer]
-                       "host_levels": result.get("host_levels")},
+                       "host_levels": result.get("host_levels"), "host_hashing": result.get("host_hashing")},
             "roofline": roofline,
             "stages": stages,
             "setup_ms": round(result["setup_ms"], 1), "device_bytes": result["device_bytes"],

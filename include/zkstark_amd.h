@@ -60,6 +60,11 @@ const char *zk_version(void);
 /* Hash of the sources and headers the library was built from (zkstark_amd/build.py: source_hash()); loaders
  * compare it with the tree to refuse a stale binary. */
 const char *zk_build_hash(void);
+/* How the host thread of the one-call provers hashes its share of the Merkle trees (the top 8 levels of every SHA-256
+ * tree and the FRI layers of <= 2^9 values, csrc/host_sha.cpp; merkle.rs:14-51 is the definition either way):
+ * 0 = portable code (then the provers leave every level to the device), 1 = x86 SHA extensions, 2 = SHA extensions plus
+ * levels of >= 16 nodes sixteen at a time on AVX-512 registers.  Decided once from the CPU; ZK_HOST_SHA_WIDE=0 keeps 1. */
+int zk_host_hash_mode(void);
 
 /* ---- scalar field helpers on the host: field.rs:8-211 ------------------- */
 uint32_t zk_field_add(uint32_t a, uint32_t b);       /* field.rs:99-111 */

@@ -111,3 +111,29 @@ def test_instruction_counts_quoted_by_bench(kd):
         assert float(re.search(name + r"\s*=\s*([0-9.]+)", hpp).group(1)) == hm["sha256"][key]
     for key, name in (("leaf_ops", "kFieldLeafOps"), ("inner_ops", "kFieldInnerOps")):
         assert float(re.search(name + r"\s*=\s*([0-9.]+)", hpp).group(1)) == hm["field"][key]
+
+
+def test_four_lane_sha256_of_the_latency_levels(kd):
+    """csrc/sha256_quad.hpp as compiled into merkle_wg_kernel: one hash is 48 x 16 + 16 x 12 + 64 x 11 round instructions,
+    544 of them DPP additions (6 / 4 / 3 per round), and the order inside a round leaves no DPP operand closer than two
+    instructions behind its producer, so no s_nop sits between the instructions of a round."""
+    import tempfile
+    text = None
+    with tempfile.TemporaryDirectory() as td:
+        for i, elf in enumerate(kd.code_objects(kd.fatbin_bytes())):
+            path = os.path.join(td, f"co{i}.elf")
+            with open(path, "wb") as f:
+                f.write(elf)
+            dis = kd._disasm(path)
+            m = re.search(r"^[0-9a-f]+ <(_ZN2zk16merkle_wg_kernelINS_8PlainSrcELb0ELi0E[^>]*)>:\n(.*?)(?=^[0-9a-f]+ <)", dis, re.S | re.M)
+            if m:
+                text = m.group(2)
+                break
+    assert text, "merkle_wg_kernel<PlainSrc, false, 0> not found"
+    ops = re.findall(r"^\s*([sv]_[a-z0-9_]+)", text, re.M)
+    assert ops.count("v_add_u32_dpp") == 48 * 6 + 16 * 4 + 64 * 3
+    # inside a round (between two DPP additions that are at most 3 instructions apart) there is never an s_nop
+    idx = [i for i, o in enumerate(ops) if o == "v_add_u32_dpp"]
+    for a, b in zip(idx, idx[1:]):
+        if b - a <= 3:
+            assert "s_nop" not in ops[a:b], ops[a:b + 1]

@@ -12,4 +12,4 @@ All device work goes through libzkstark_amd.so; there is no CPU fallback.
 """
 from ._lib import ZkError, load  # noqa: F401
 from .host import (P, BatchContext, Channel, Context, Merkle, Proof, compute_root_from_path, field, generate_proof,  # noqa: F401
-                   lde, ntt, probe_hash_chain, prove_many, shard_plan, shard_unique_id, ShardContext, trace_fibsq, trace_fibsq_batch)
+                   host_hash_mode, lde, ntt, probe_hash_chain, prove_many, shard_plan, shard_unique_id, ShardContext, trace_fibsq, trace_fibsq_batch)

@@ -72,6 +72,7 @@ SYMBOLS = {
     "zk_last_error": (_cp, []),
     "zk_version": (_cp, []),
     "zk_build_hash": (_cp, []),
+    "zk_host_hash_mode": (C.c_int, []),
     "zk_field_add": (_u32, [_u32, _u32]),
     "zk_field_sub": (_u32, [_u32, _u32]),
     "zk_field_mul": (_u32, [_u32, _u32]),

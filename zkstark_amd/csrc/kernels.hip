@@ -768,6 +768,7 @@ static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t h
     return (x < lo || x > hi) ? dflt : x;
 }
 // Tuning switches (environment, read once).  ZK_MERKLE_MAX_K: levels per subtree launch.
+uint32_t ntt_small_tile_max_log() { static const uint32_t v = env_u32("ZK_NTT_SMALL_MAX_LOG", 20, 12, 30); return v; }
 static uint32_t merkle_max_k() { static const uint32_t v = env_u32("ZK_MERKLE_MAX_K", kMerkleMaxK, 1, kMerkleMaxK); return v; }
 static uint32_t merkle_latency_log() { static const uint32_t v = env_u32("ZK_MERKLE_LATENCY_LOG", kMerkleLatencyLogDefault, 12, 24); return v; }
 

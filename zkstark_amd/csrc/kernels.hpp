@@ -82,7 +82,8 @@ enum NttMode : uint32_t {
 // per thread).  At 2^21 the small tile was 12 % faster but fetched 2 x the bytes (64-byte row segments at radix 128,
 // PMC FETCH_SIZE), so the switch sits below that size.
 constexpr uint32_t kBigTileLog = 13, kSmallTileLog = 11;
-inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total > 20 ? kBigTileLog : kSmallTileLog; }
+uint32_t ntt_small_tile_max_log();   // transforms of up to 2^this words use the small tile (kernels.hip; ZK_NTT_SMALL_MAX_LOG)
+inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total > ntt_small_tile_max_log() ? kBigTileLog : kSmallTileLog; }
 
 struct NttPassArgs {
     const uint32_t* src;

@@ -501,6 +501,7 @@ int prove_resident(zk_ctx* c, Channel& ch) {
 extern "C" {
 
 const char* zk_last_error(void) { return last_error(); }
+int zk_host_hash_mode(void) { return host_sha_wide_available() ? 2 : host_sha_available() ? 1 : 0; }
 
 uint32_t zk_field_add(uint32_t a, uint32_t b) { return add(a % P, b % P); }
 uint32_t zk_field_sub(uint32_t a, uint32_t b) { return sub(a % P, b % P); }

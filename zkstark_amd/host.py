@@ -49,6 +49,12 @@ class field:
     def order(a): return _lib.load().zk_field_order(a)     # field.rs:45-49
 
 
+def host_hash_mode():
+    """How the host thread hashes its share of the trees: 'portable' (then everything stays on the device),
+    'sha-ni', or 'sha-ni + avx512 x16' (levels of >= 16 nodes sixteen at a time); zk_host_hash_mode."""
+    return ("portable", "sha-ni", "sha-ni + avx512 x16")[_lib.load().zk_host_hash_mode()]
+
+
 def probe_hash_chain(hash="sha256", waves_per_simd=4, hashes=16, launches=10, device=0):
     """Roofline probe (zk_probe_hash_chain): steady-state rate of the compiled inner hash in a dependent chain."""
     r = _lib.ChainProbe()
