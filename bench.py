@@ -599,6 +599,11 @@ def main():
                     "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1)},
             "valu": valu,
         }
+        if sharded_run and (result.get("shard") or {}).get("chunked_layers"):
+            # chunk builds of a layer alternate between two streams (csrc/shard.hip): a launch's HIP-event duration then
+            # includes the time it shares the chip with its neighbour, so achieved / frac are LOWER bounds on this line
+            roofline["note"] += ("; sharded run with chunked layers: the chunk launches of a layer run two at a time on two streams, the per-launch "
+                                 "durations overlap and achieved / frac are lower bounds (ZK_SHARD_ONE_BUILD_STREAM=1 gives unshared launches)")
         # the hashing of one proof against its floor: every Merkle launch of the per-stage proof, and the time the same
         # instruction count needs at the chain rate (a floor the kernels cannot beat by construction)
         pk = result["per_kernel"]
