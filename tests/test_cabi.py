@@ -252,3 +252,21 @@ def test_shard_plan_is_the_one_layout(zk):
     # the mirror holds no thresholds of its own
     src = open(os.path.join(ROOT, "zkstark_amd", "sharded.py")).read()
     assert "shard_plan(" in src and "chunk_min_log" not in src
+
+
+def test_host_hash_mode_follows_the_cpu(zk):
+    """zk_host_hash_mode: 0 portable, 1 x86 SHA extensions, 2 + AVX-512 (sixteen nodes at a time); it must agree with
+    what the CPU advertises, because the provers hand tree tops to the host thread only when it returns >= 1."""
+    flags = set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    break
+    except OSError:
+        pytest.skip("no /proc/cpuinfo")
+    want = 0
+    if {"sha_ni", "sse4_1", "ssse3"} <= flags:
+        want = 2 if "avx512f" in flags and os.environ.get("ZK_HOST_SHA_WIDE", "1") != "0" else 1
+    assert zk.host_hash_mode() == ("portable", "sha-ni", "sha-ni + avx512 x16")[want]
