@@ -298,7 +298,7 @@ typedef struct zk_shard_transport {
 typedef struct zk_shard_options {   /* zero = default */
     uint32_t min_layer_log;     /* a FRI layer stays sharded while it has >= 2^this values in total (22) */
     uint32_t min_chunk_log;     /* ... and >= 2^this leaves per (rank, peer) piece (14) */
-    uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (22) */
+    uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (21) */
     int force_collectives;      /* run the collectives even with world = 1 (exercises the transport on one GPU) */
     int no_root_board;          /* exchange subtree roots with an all-gather instead of the shared-memory board */
 } zk_shard_options;

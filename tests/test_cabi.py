@@ -231,7 +231,7 @@ def test_shard_plan_is_the_one_layout(zk):
     """zk_shard_plan (no GPU): the layout both the native sharded prover and the torch.distributed mirror follow.
     The benchmark's weak-scaling configurations, the byte formula of DESIGN.md section 6, and the mirror's view of it."""
     # bench.py --gpus 2 / 4 / 8 (2^24 elements per GPU, production thresholds): GPU tests assert the same numbers on the prover's stats
-    for world, log_n, want_sharded, want_chunked in ((2, 22, 4, 3), (4, 23, 5, 2), (8, 24, 6, 0), (8, 21, 3, 0), (1, 21, 3, 0)):
+    for world, log_n, want_sharded, want_chunked in ((2, 22, 4, 4), (4, 23, 5, 3), (8, 24, 6, 2), (8, 21, 3, 0), (1, 21, 3, 0)):
         pl = zk.shard_plan(world, log_n, 3)
         assert (pl["sharded_layers"], pl["chunked_layers"]) == (want_sharded, want_chunked), (world, log_n, pl)
         assert pl["tail_rounds"] == log_n - want_sharded and pl["log_chunks"] == 2

@@ -114,7 +114,7 @@ struct zk_shard {
     ncclComm_t comm = nullptr;
     bool force = false;                                // collectives even with G = 1
     // layout
-    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 22;
+    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 21;
     static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
     uint32_t n_sharded = 1, tail_rounds = 0, chunked_mask = 0;   // zk_shard_plan
     zk_dom* dom_loc = nullptr;
@@ -553,7 +553,7 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
     while ((1 << lg) < world) ++lg;
     if ((1 << lg) != world || lg > log_b)
         return fail(ZK_ERR_INVALID, "zk_shard_plan: world size %d must be a power of two dividing the blow-up %u", world, 1u << log_b);
-    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 22;
+    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 21;
     bool force = false;
     if (opt) {
         if (opt->min_layer_log) min_layer_log = opt->min_layer_log;

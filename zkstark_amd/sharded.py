@@ -379,7 +379,7 @@ class HipBackend:
 class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
 
-    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=None, overlap_min_log=22, min_layer_log=None, use_board=True):
+    def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=None, overlap_min_log=0, min_layer_log=None, use_board=True):
         import os
         if os.environ.get("ZK_SHARD_PLAIN") == "1":    # operational switch: plain collectives only
             overlap_min_log, use_board = 99, False
