@@ -860,10 +860,16 @@ hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_pa
 // next chunk); everything above -- further throughput launches and the latency phase -- runs once over the whole tree,
 // at full width.  (Round 2 let every chunk run its own inner launches down to the latency switch: four quarter-width
 // launches per level group, each a quarter-filled chip.)  Trees too small for that hand over at the chunk roots.
+// A chunk build takes k = 3 levels, not 4: a chunk of 2^22 leaves is then 2 048 workgroups of 32 KiB of LDS (1.6 rounds
+// of five per CU) instead of 1 024 of 40 KiB that start and end together, so LDS frees up all through the launch and the
+// workgroups of the exchange kernel that runs beside it (rcclGenericKernel: 64 x 256 threads, 19.5 KiB of LDS each,
+// measured) find room on the CUs.  The hashing rate does not depend on k (profiles/r03_ab_max_k.txt).
+static uint32_t merkle_chunk_k() { static const uint32_t v = env_u32("ZK_MERKLE_CHUNK_K", 3, 1, kMerkleMaxK); return v; }
 static uint32_t chunk_handover_depth(uint32_t log_m, uint32_t log_chunks) {
     const uint32_t lat = merkle_latency_log();
     if (!(log_m > lat && lat >= log_chunks + 8)) return log_chunks;
-    const uint32_t k = log_m - lat < merkle_max_k() ? log_m - lat : merkle_max_k();
+    uint32_t k = log_m - lat < merkle_max_k() ? log_m - lat : merkle_max_k();
+    if (k > merkle_chunk_k()) k = merkle_chunk_k();
     return log_m - k;
 }
 uint32_t merkle_finish_start_depth(uint32_t log_m, uint32_t log_chunks) { return chunk_handover_depth(log_m, log_chunks); }

@@ -667,7 +667,11 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     s->chunked_mask = plan.chunked_mask;
     (void)R;
     HIPCHK_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIPCHK_S(hipStreamCreateWithFlags(&s->xstream, hipStreamNonBlocking));
+    {   // the exchanges run beside the hashing: their workgroups should win the CU slots the hashing frees
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        HIPCHK_S(hipStreamCreateWithPriority(&s->xstream, hipStreamNonBlocking, greatest));
+    }
     HIPCHK_S(hipEventCreateWithFlags(&s->ev_layer, hipEventDisableTiming));
     for (hipEvent_t& e : s->ev_chunk) HIPCHK_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : s->ev_built) HIPCHK_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
