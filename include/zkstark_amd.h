@@ -63,8 +63,12 @@ const char *zk_build_hash(void);
 /* How the host thread of the one-call provers hashes its share of the Merkle trees (the top 8 levels of every SHA-256
  * tree and the FRI layers of <= 2^9 values, csrc/host_sha.cpp; merkle.rs:14-51 is the definition either way):
  * 0 = portable code (then the provers leave every level to the device), 1 = x86 SHA extensions, 2 = SHA extensions plus
- * levels of >= 16 nodes sixteen at a time on AVX-512 registers.  Decided once from the CPU; ZK_HOST_SHA_WIDE=0 keeps 1. */
+ * levels of >= 16 nodes sixteen at a time on AVX-512 registers.  Decided once from the CPU. */
 int zk_host_hash_mode(void);
+/* Restricts the host's hashing to `mode` (0, 1 or 2 as above; never more than the CPU has): 0 makes later contexts
+ * leave every tree level to the device, 1 keeps the SHA unit but not the AVX-512 path (A/B measurements, tests).
+ * Process-wide; call it while no prover is running and before the contexts it should affect are created. */
+int zk_host_set_hash_mode(int mode);
 
 /* ---- scalar field helpers on the host: field.rs:8-211 ------------------- */
 uint32_t zk_field_add(uint32_t a, uint32_t b);       /* field.rs:99-111 */
@@ -210,6 +214,11 @@ size_t zk_batch_size(const zk_batch *b);                    /* 2^log_batch */
 /* As zk_ctx_set_queries (1..16 here) and zk_ctx_set_hash, for every proof of the batch. */
 int zk_batch_set_queries(zk_batch *b, uint32_t n_queries);
 int zk_batch_set_hash(zk_batch *b, int hash_kind);
+/* on = 0: every tree level of the batch on the device (default: the host threads hash the top levels of each proof's
+ * trees when the CPU has SHA extensions, as zk_ctx_set_host_levels).  Results are identical. */
+int zk_batch_set_host_levels(zk_batch *b, int on);
+/* Host threads that run the per-proof transcript steps and decommit hashing (default: hardware threads, at most 16). */
+int zk_batch_set_threads(zk_batch *b, uint32_t threads);
 size_t zk_batch_device_bytes(const zk_batch *b);
 /* traces: [batch][n-1] canonical residues (prover.rs:32-39 per proof), uploaded and kept resident. */
 int zk_batch_set_traces(zk_batch *b, const uint32_t *traces);
@@ -301,6 +310,13 @@ typedef struct zk_shard_options {   /* zero = default */
     uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (21) */
     int force_collectives;      /* run the collectives even with world = 1 (exercises the transport on one GPU) */
     int no_root_board;          /* exchange subtree roots with an all-gather instead of the shared-memory board */
+    int plain_collectives;      /* no chunked exchange and no shared-memory roots: one all-to-all per layer on the main
+                                   stream, subtree roots by all-gather (the fall-back rung of bench.py --gpus N) */
+    int single_build_stream;    /* chunk builds of a layer on one stream (A/B; default: two alternating streams) */
+    int single_communicator;    /* built-in RCCL transport: the exchange stream shares the main communicator (default: the
+                                   chunked exchanges get a communicator of their own, see below) */
+    int reserved;
+    double timeout_s;           /* bound of every host-side wait on a peer; 0 = environment ZK_SHARD_TIMEOUT_S, else 120 s */
 } zk_shard_options;
 typedef struct zk_shard_stats {
     uint32_t sharded_layers;    /* FRI layers 0 .. sharded_layers-1 (and f) are distributed; the rest is the replicated tail */
@@ -308,11 +324,23 @@ typedef struct zk_shard_stats {
     uint32_t chunked_layers;    /* layers of the last proof exchanged in chunks overlapped with the hashing */
     uint32_t native_rccl;       /* 1: the built-in RCCL transport */
     uint32_t rccl_nranks;       /* ncclCommCount of the communicator (checked against `world` at creation); 0 without RCCL */
-    uint32_t reserved;
+    uint32_t communicators;     /* RCCL communicators in use: 2 when the chunked exchanges have their own, else 1; 0 without RCCL */
     double sent_bytes;          /* bytes this rank sent to OTHER ranks during the last zk_shard_prove* / lde_commit */
     double all_to_all_bytes;    /* ... of which in the per-commitment all-to-alls */
     double setup_ms;
     double device_bytes;
+    /* zk_shard_set_profiling(s, 1): HIP events around the exchanges of the last zk_shard_prove* / lde_commit (0 otherwise).
+     * exchange_ms: summed durations of the all-to-alls and all-gathers on their streams (for a chunked layer this includes
+     * the time the exchange kernel waits for compute units beside the hashing); exposed_exchange_ms: the part of it the
+     * hashing streams spent stalled (a plain exchange is exposed in full, a chunk only while its build waits for it);
+     * tail_ms: host time of the replicated tail (all-gather of the first replicated layer, then zk_tail_run);
+     * selftest_ms: the known-pattern exchange run by zk_shard_create. */
+    double exchange_ms;
+    double exposed_exchange_ms;
+    double tail_ms;
+    double selftest_ms;
+    uint32_t exchanges;         /* collectives timed (profiling on) */
+    uint32_t selftest_ok;       /* 1: zk_shard_create's known-pattern all-to-all + all-gather arrived in the right places */
 } zk_shard_stats;
 /* The layout of a sharded proof, as a pure function of its arguments (no GPU, no communication): what
  * zk_shard_create will do.  Layer ids: 0 = f_eval, 1 + r = FRI layer r. */
@@ -324,7 +352,7 @@ typedef struct zk_shard_plan_info {
     uint32_t chunked_layers;     /* committed layers exchanged in chunks overlapped with the hashing */
     uint32_t chunked_mask;       /* bit id set: layer id is exchanged in chunks */
     uint32_t log_chunks;         /* a chunked layer is exchanged in 2^log_chunks chunks */
-    uint32_t min_layer_log;      /* the thresholds in force (options, defaults, ZK_SHARD_PLAIN) */
+    uint32_t min_layer_log;      /* the thresholds in force (options and defaults; plain_collectives: overlap_min_log = 99) */
     uint32_t min_chunk_log;
     uint32_t overlap_min_log;
     uint32_t piece_log[32];      /* log2 words of one (rank, peer) piece of layer id */
@@ -332,7 +360,20 @@ typedef struct zk_shard_plan_info {
     double lde_commit_bytes;     /* ... of zk_shard_lde_commit (layer 0 only) */
 } zk_shard_plan_info;
 int zk_shard_plan(int world, uint32_t log_n, uint32_t log_blowup, const zk_shard_options *opt, zk_shard_plan_info *out);
-/* ncclGetUniqueId through the same run-time loaded RCCL (rank 0, before zk_shard_create). */
+/* Streams and communicators.  Plain exchanges run on the prover's main stream.  Chunked exchanges (pieces of >=
+ * 2^overlap_min_log words) run on a second, high-priority stream beside the hashing; with the built-in transport they use a
+ * second RCCL communicator created for that stream (rank 0 draws its id and the first communicator distributes it), so no
+ * communicator is ever driven from two streams, and every collective additionally waits (HIP event) for the previous
+ * collective of the other stream, so no ordering rests on RCCL's internal serialisation.  A caller transport is called
+ * with either stream and must tolerate that.
+ * zk_shard_create ends with a self-test when collectives are in use: an all-to-all (on each stream in use) and an
+ * all-gather of a known pattern at the size of the largest piece; every word must arrive at its place, else the call
+ * fails with ZK_ERR_HIP naming the first wrong (peer, word).  It also brings RCCL's lazy connections up before the
+ * first proof.  zk_shard_self_test repeats it on request.
+ * ncclCommInitRank itself is not bounded by this library (it cannot be cancelled): a caller that must not hang runs
+ * its ranks under a watchdog (bench.py does).
+ *
+ * ncclGetUniqueId through the same run-time loaded RCCL (rank 0, before zk_shard_create). */
 int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]);
 /* Collective over the `world` ranks (ncclCommInitRank when transport is NULL).  id: the shared 128 bytes; with a
  * caller transport they only name the shared-memory root board (NULL: no board).  opt may be NULL. */
@@ -351,10 +392,18 @@ int zk_shard_lde_commit(zk_shard *s, uint8_t root_out[32]);
 int zk_shard_set_hash(zk_shard *s, int hash_kind);
 int zk_shard_set_queries(zk_shard *s, uint32_t n_queries);
 /* Failure handling.  A rank that leaves zk_shard_prove* / zk_shard_lde_commit with an error posts an abort on the shared
- * root board (peers waiting for it return ZK_ERR_HIP naming this rank instead of waiting out ZK_SHARD_TIMEOUT_S, default
- * 120 s), refuses further proofs, and zk_shard_destroy then aborts its RCCL communicator (ncclCommAbort).
+ * root board (peers waiting for it return ZK_ERR_HIP naming this rank instead of waiting out zk_shard_options.timeout_s),
+ * refuses further proofs, and zk_shard_destroy then aborts its RCCL communicators (ncclCommAbort).  The board's abort
+ * words are mapped whenever the ranks share a node, also when the roots themselves travel by all-gather
+ * (no_root_board, plain_collectives).  With a caller transport nothing can abort a collective that is already
+ * enqueued: zk_shard_destroy of a failed prover then does not wait for its streams (they are leaked with a message).
  * zk_shard_inject_failure makes a rank fail that way on purpose (tests). */
 int zk_shard_inject_failure(zk_shard *s, int code);
+/* Known-pattern all-to-all + all-gather through the prover's transport (collective; see above). */
+int zk_shard_self_test(zk_shard *s);
+/* on != 0: time the exchanges of later proofs with HIP events (zk_shard_stats.exchange_ms ...); costs a few event
+ * records per layer, so benchmarks switch it on for one untimed proof. */
+int zk_shard_set_profiling(zk_shard *s, int on);
 int zk_shard_last_transcript(const zk_shard *s, zk_transcript_info *out);
 /* This rank's shard of a layer (0 = f_eval, 1 + r = FRI layer r < sharded_layers): element j is global index
  * rank + world * j. */
@@ -439,6 +488,8 @@ int zk_dev_merkle_build_interleaved(const uint32_t *d_recv, uint32_t log_parts, 
 typedef struct zk_committer zk_committer;
 int zk_committer_create(int device, zk_committer **out);
 int zk_committer_destroy(zk_committer *k);
+/* Hand-over depth of later commits (top_log of zk_ctx_set_host_levels; <= 8; 0 = the device builds to the root). */
+int zk_committer_set_top(zk_committer *k, uint32_t top_log);
 int zk_dev_merkle_commit(zk_committer *k, const uint32_t *d_src, uint32_t log_parts, uint32_t log_cnt,
                          uint32_t *d_nodes, void *stream, int hash_kind, uint8_t root_out[32]);
 /* zk_dev_merkle_finish with the same hand-over: for a tree built with zk_dev_merkle_build_chunk. */
@@ -451,6 +502,11 @@ int zk_dev_merkle_commit_finish(zk_committer *k, uint32_t *d_nodes, uint32_t log
 int zk_dev_merkle_build_chunk(const uint32_t *d_recv, uint32_t log_parts, uint32_t log_cnt, uint32_t *d_nodes,
                               uint32_t log_m, uint32_t chunk, void *stream, int hash_kind);
 int zk_dev_merkle_finish(uint32_t *d_nodes, uint32_t log_m, uint32_t log_chunks, void *stream, int hash_kind);
+/* Tuning / test hook, process-wide: a Merkle build runs throughput launches (a wave owns 64 * 2^k leaves) while a level
+ * has more than 2^log_nodes nodes and finishes the tree in workgroup-local launches below that (default 17: measured
+ * flat between 16 and 18; 0 restores the default; 12 .. 24).  Results do not depend on it; tests lower it to drive
+ * small trees through the chunked build (zk_dev_merkle_build_chunk / _finish).  Call it while no build is in flight. */
+int zk_dev_set_merkle_latency_log(uint32_t log_nodes);
 /* Byte view of nodes stored as state words: out[32] for node `index`. */
 int zk_dev_merkle_node(const uint32_t *d_nodes, size_t index, uint8_t out[32], void *stream);
 

@@ -91,6 +91,7 @@ def lib():
         L.orc_compute_root_from_path.restype = None
         L.orc_compute_root_from_path.argtypes = [u32, sz, vp, sz, vp]
         L.orc_set_hash.restype = None; L.orc_set_hash.argtypes = [C.c_int]
+        L.orc_set_fieldhash_batch.restype = None; L.orc_set_fieldhash_batch.argtypes = [C.c_int]
         L.orc_fieldhash_permute.restype = None; L.orc_fieldhash_permute.argtypes = [vp]
         L.orc_prove.restype = C.c_int
         L.orc_prove.argtypes = [u32, u32, u32, u32, C.c_int, vp, sz, C.POINTER(sz), vp, C.POINTER(_Debug)]
@@ -239,6 +240,12 @@ def sha256(msg: bytes) -> bytes:
     out = C.create_string_buffer(32)
     lib().orc_sha256(msg, len(msg), out)
     return out.raw
+
+
+def set_fieldhash_batch(on):
+    """Field hash in orc_merkle_build: eight hashes at a time in exact double arithmetic on AVX-512 registers (default on
+    where the CPU has AVX-512F) or the scalar plain-residue code; the digests are the same (tests pin one on the other)."""
+    lib().orc_set_fieldhash_batch(int(bool(on)))
 
 
 def merkle_build(vals):

@@ -652,6 +652,117 @@ static void fh_digest(const uint32_t in[16], uint8_t out[32]) {
 }
 static uint32_t fh_word(const uint8_t *p) { return (((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]) % ORC_P; }
 
+/* ---- the same permutation, EIGHT hashes at a time, in exact double-precision arithmetic ---------------------------
+ * Test infrastructure for BASELINE.json configs[4] at its stated size (domain 2^24 = 10^8 hashes per proof): the scalar
+ * code above manages ~0.3 M hashes/s per core.  This form is still a plain-residue restatement and shares nothing with
+ * the GPU code (which is 32-bit Montgomery): every state element is an integer held exactly in a double (< 2^53),
+ * linear layers accumulate without reduction and reduce once, and a product a*b mod P is formed from the exact
+ * split a*b = h + l (h = fl(a*b), l = fma(a, b, -h)) and the quotient estimate q = rint(h / P):
+ *     r = fma(-q, P, h) + l   is exactly a*b - q*P,  |r| < P.
+ * The eight lanes of an AVX-512 register are eight independent hashes (x86-64 with AVX-512F only; any other CPU keeps
+ * the scalar code).  tests/test_oracle_reference.py pins it against the scalar code above on random values and on
+ * whole trees; orc_set_fieldhash_batch(0) switches it off. */
+#define FHW 8
+static int g_fh_batch = 1;
+void orc_set_fieldhash_batch(int on) { g_fh_batch = on != 0; }
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define FH_HAVE_BATCH 1
+#define FH_AVX512 __attribute__((target("avx512f"), always_inline)) static inline
+typedef __m512d fhv;                                   /* one state element of eight hashes */
+/* x (an integer, |x| < 2^51) -> x mod P in [0, P) */
+FH_AVX512 fhv fhd_reduce(fhv x, fhv vp, fhv vinvp) {
+    fhv q = _mm512_roundscale_pd(_mm512_mul_pd(x, vinvp), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+    fhv r = _mm512_fnmadd_pd(q, vp, x);                /* exact: |x - q P| <= P/2 + 1 */
+    return _mm512_mask_add_pd(r, _mm512_cmp_pd_mask(r, _mm512_setzero_pd(), _CMP_LT_OQ), r, vp);
+}
+/* a, b in [0, P) -> a*b mod P in [0, P) */
+FH_AVX512 fhv fhd_mul(fhv a, fhv b, fhv vp, fhv vinvp) {
+    fhv h = _mm512_mul_pd(a, b);
+    fhv l = _mm512_fmsub_pd(a, b, h);                  /* a*b = h + l exactly */
+    fhv q = _mm512_roundscale_pd(_mm512_mul_pd(h, vinvp), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+    fhv r = _mm512_add_pd(_mm512_fnmadd_pd(q, vp, h), l);   /* exactly a*b - q*P, |.| < P */
+    return _mm512_mask_add_pd(r, _mm512_cmp_pd_mask(r, _mm512_setzero_pd(), _CMP_LT_OQ), r, vp);
+}
+/* (x + c)^5, x and c in [0, P) */
+FH_AVX512 fhv fhd_sbox(fhv x, fhv c, fhv vp, fhv vinvp) {
+    x = _mm512_add_pd(x, c);
+    x = _mm512_mask_sub_pd(x, _mm512_cmp_pd_mask(x, vp, _CMP_GE_OQ), x, vp);
+    fhv x2 = fhd_mul(x, x, vp, vinvp);
+    return fhd_mul(fhd_mul(x2, x2, vp, vinvp), x, vp, vinvp);
+}
+/* fh_m4 + the column sums of fh_external, unreduced (coefficients sum to < 2^6: values < 2^38), then one reduction */
+FH_AVX512 void fhd_external(fhv s[FH_T], fhv vp, fhv vinvp) {
+    const fhv two = _mm512_set1_pd(2.0), four = _mm512_set1_pd(4.0);
+    for (int b = 0; b < 4; ++b) {
+        fhv x0 = s[4 * b], x1 = s[4 * b + 1], x2 = s[4 * b + 2], x3 = s[4 * b + 3];
+        fhv t0 = _mm512_add_pd(x0, x1), t1 = _mm512_add_pd(x2, x3);
+        fhv t2 = _mm512_fmadd_pd(two, x1, t1), t3 = _mm512_fmadd_pd(two, x3, t0);     /* small integers: exact */
+        fhv t4 = _mm512_fmadd_pd(four, t1, t3), t5 = _mm512_fmadd_pd(four, t0, t2);
+        s[4 * b] = _mm512_add_pd(t3, t5); s[4 * b + 1] = t5; s[4 * b + 2] = _mm512_add_pd(t2, t4); s[4 * b + 3] = t4;
+    }
+    for (int j = 0; j < 4; ++j) {
+        fhv col = _mm512_add_pd(_mm512_add_pd(s[j], s[4 + j]), _mm512_add_pd(s[8 + j], s[12 + j]));
+        for (int b = 0; b < 4; ++b) s[4 * b + j] = fhd_reduce(_mm512_add_pd(s[4 * b + j], col), vp, vinvp);
+    }
+}
+FH_AVX512 void fhd_internal(fhv s[FH_T], fhv vp, fhv vinvp) {
+    fhv sum = s[0];
+    for (int i = 1; i < FH_T; ++i) sum = _mm512_add_pd(sum, s[i]);                       /* < 2^36 */
+    s[0] = fhd_reduce(_mm512_fnmadd_pd(_mm512_set1_pd(2.0), s[0], sum), vp, vinvp);      /* diag[0] = P - 2 = -2 */
+    for (int i = 1; i < FH_T; ++i) s[i] = fhd_reduce(_mm512_fmadd_pd(s[i], _mm512_set1_pd((double)(1u << (i - 1))), sum), vp, vinvp);   /* diag[i] = 2^(i-1): < 2^47 */
+}
+/* orc_fieldhash_permute on eight states at once: st[i * 8 + h] = element i of hash h */
+__attribute__((target("avx512f")))
+static void fhd_permute(double *st, const double rcf[FH_RF][FH_T], const double rcp[FH_RP]) {
+    const fhv vp = _mm512_set1_pd(3221225473.0), vinvp = _mm512_set1_pd(1.0 / 3221225473.0);
+    fhv s[FH_T];
+    for (int i = 0; i < FH_T; ++i) s[i] = _mm512_loadu_pd(st + 8 * i);
+    fhd_external(s, vp, vinvp);
+    for (int r = 0; r < FH_RF / 2; ++r) {
+        for (int i = 0; i < FH_T; ++i) s[i] = fhd_sbox(s[i], _mm512_set1_pd(rcf[r][i]), vp, vinvp);
+        fhd_external(s, vp, vinvp);
+    }
+    for (int r = 0; r < FH_RP; ++r) {
+        s[0] = fhd_sbox(s[0], _mm512_set1_pd(rcp[r]), vp, vinvp);
+        fhd_internal(s, vp, vinvp);
+    }
+    for (int r = FH_RF / 2; r < FH_RF; ++r) {
+        for (int i = 0; i < FH_T; ++i) s[i] = fhd_sbox(s[i], _mm512_set1_pd(rcf[r][i]), vp, vinvp);
+        fhd_external(s, vp, vinvp);
+    }
+    for (int i = 0; i < FH_T; ++i) _mm512_storeu_pd(st + 8 * i, s[i]);
+}
+static int fh_batch_usable(void) { return g_fh_batch && __builtin_cpu_supports("avx512f"); }
+#else
+#define FH_HAVE_BATCH 0
+static void fhd_permute(double *st, const double rcf[FH_RF][FH_T], const double rcp[FH_RP]) { (void)st; (void)rcf; (void)rcp; }
+static int fh_batch_usable(void) { return 0; }
+#endif
+/* digests of FHW states in[h][16] (canonical residues) -> out + 32 h */
+static void fh_digest_batch(uint32_t in[FHW][FH_T], uint8_t *out) {
+    static double rcf[FH_RF][FH_T], rcp[FH_RP];
+    static int ready = 0;
+    if (!ready) {
+#pragma omp critical(fh_batch_init)
+        if (!ready) {
+            fh_init();
+            for (int r = 0; r < FH_RF; ++r) for (int i = 0; i < FH_T; ++i) rcf[r][i] = (double)fh_rc_full[r][i];
+            for (int r = 0; r < FH_RP; ++r) rcp[r] = (double)fh_rc_part[r];
+            __atomic_store_n(&ready, 1, __ATOMIC_RELEASE);
+        }
+    }
+    double s[FH_T * FHW];
+    for (int h = 0; h < FHW; ++h) for (int i = 0; i < FH_T; ++i) s[i * FHW + h] = (double)in[h][i];
+    fhd_permute(s, rcf, rcp);
+    for (int h = 0; h < FHW; ++h)
+        for (int i = 0; i < 8; ++i) {
+            uint32_t v = fadd((uint32_t)s[i * FHW + h], in[h][i]);
+            uint8_t *o = out + 32 * h + 4 * i;
+            o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v;
+        }
+}
+
 /* ======================================================================== */
 /* merkle.rs                                                                */
 /* ======================================================================== */
@@ -687,10 +798,34 @@ void orc_node_hash(const uint8_t *l, const uint8_t *r, uint8_t out[32]) { node_h
 int orc_merkle_build(const uint32_t *vals, size_t m, uint8_t *nodes) {
     if (m == 0 || (m & (m - 1))) return -1;          /* merkle.rs:16-21 assert */
     size_t total = 2 * m - 1, offset = total / 2;    /* merkle.rs:27 */
+    const int batch = g_hash_kind == ORC_HASH_FIELD && fh_batch_usable();     /* eight field hashes at a time (same digests) */
+    if (batch && m >= FHW) {
 #pragma omp parallel for schedule(static) if (m >= 4096)
-    for (size_t i = 0; i < m; ++i) leaf_hash(vals[i], nodes + 32 * (offset + i));
+        for (size_t i0 = 0; i0 < m; i0 += FHW) {
+            uint32_t in[FHW][FH_T];
+            memset(in, 0, sizeof in);
+            for (int h = 0; h < FHW; ++h) { in[h][0] = vals[i0 + h] % ORC_P; in[h][15] = 1; }   /* leaf_hash's state */
+            fh_digest_batch(in, nodes + 32 * (offset + i0));
+        }
+    } else {
+#pragma omp parallel for schedule(static) if (m >= 4096)
+        for (size_t i = 0; i < m; ++i) leaf_hash(vals[i], nodes + 32 * (offset + i));
+    }
     while (offset > 0) {                              /* merkle.rs:38-47 */
         offset /= 2;
+        if (batch && offset + 1 >= FHW) {
+#pragma omp parallel for schedule(static) if (offset >= 2048)
+            for (size_t it = 0; it < offset + 1; it += FHW) {
+                uint32_t in[FHW][FH_T];
+                for (int h = 0; h < FHW; ++h) {
+                    const size_t idx = offset + it + h;
+                    const uint8_t *lc = nodes + 32 * (2 * idx + 1), *rc = nodes + 32 * (2 * idx + 2);   /* node_hash's state */
+                    for (int i = 0; i < 8; ++i) { in[h][i] = fh_word(lc + 4 * i); in[h][8 + i] = fh_word(rc + 4 * i); }
+                }
+                fh_digest_batch(in, nodes + 32 * (offset + it));
+            }
+            continue;
+        }
 #pragma omp parallel for schedule(static) if (offset >= 2048)
         for (size_t it = 0; it < offset + 1; ++it) {
             size_t idx = offset + it;

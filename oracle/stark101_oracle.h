@@ -99,6 +99,9 @@ void orc_compute_root_from_path(uint32_t element, size_t index, const uint8_t *p
  * self-defined, no reference counterpart).  The transcript always hashes with SHA-256. */
 void orc_set_hash(int kind);
 void orc_fieldhash_permute(uint32_t state[16]);
+/* orc_merkle_build with the field hash: eight hashes at a time in exact double arithmetic on AVX-512 registers (default
+ * on where the CPU has AVX-512F; same digests as the scalar code, which on = 0 selects). */
+void orc_set_fieldhash_batch(int on);
 
 /* ---- channel.rs -------------------------------------------------------- */
 typedef struct orc_channel {

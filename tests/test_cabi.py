@@ -249,9 +249,11 @@ def test_shard_plan_is_the_one_layout(zk):
         with pytest.raises(zk.ZkError) as e:
             zk.shard_plan(*bad)
         assert e.value.code == -1
-    # the mirror holds no thresholds of its own
-    src = open(os.path.join(ROOT, "zkstark_amd", "sharded.py")).read()
+    # the mirror (test infrastructure since round 4) holds no thresholds of its own, and the package holds no second prover
+    src = open(os.path.join(ROOT, "tests", "sharded_mirror.py")).read()
     assert "shard_plan(" in src and "chunk_min_log" not in src
+    pkg = open(os.path.join(ROOT, "zkstark_amd", "sharded.py")).read()
+    assert "class ShardedProver" not in pkg and "def staged_transport" in pkg and "def device_transport" in pkg
 
 
 def test_host_hash_mode_follows_the_cpu(zk):
@@ -268,5 +270,16 @@ def test_host_hash_mode_follows_the_cpu(zk):
         pytest.skip("no /proc/cpuinfo")
     want = 0
     if {"sha_ni", "sse4_1", "ssse3"} <= flags:
-        want = 2 if "avx512f" in flags and os.environ.get("ZK_HOST_SHA_WIDE", "1") != "0" else 1
-    assert zk.host_hash_mode() == ("portable", "sha-ni", "sha-ni + avx512 x16")[want]
+        want = 2 if "avx512f" in flags else 1
+    names = ("portable", "sha-ni", "sha-ni + avx512 x16")
+    assert zk.host_hash_mode() == names[want]
+    # zk_host_set_hash_mode: never more than the CPU has, and the narrow setting survives switching the extensions on again
+    lib = zk.load()
+    try:
+        for mode in (0, 1, 2):
+            assert lib.zk_host_set_hash_mode(mode) == 0
+            assert zk.host_hash_mode() == names[min(mode, want)]
+        assert lib.zk_host_set_hash_mode(3) == -1
+    finally:
+        lib.zk_host_set_hash_mode(2)
+    assert zk.host_hash_mode() == names[want]

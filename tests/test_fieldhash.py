@@ -47,6 +47,31 @@ def test_permutation_is_a_bijection_on_samples(field_oracle):
     assert field_oracle.fieldhash_permute(np.zeros(16, dtype=np.uint32)).any()
 
 
+def test_oracle_batched_fieldhash_equals_the_scalar_one(field_oracle):
+    """The oracle hashes eight nodes at a time in exact double arithmetic (AVX-512) so that configs[4] can be compared
+    byte for byte at domain 2^24; that path is pinned here on the scalar plain-residue code: whole trees over random
+    values and the edge residues, and a whole proof."""
+    rng = np.random.default_rng(404)
+    for log_m in (3, 4, 7, 12, 15):
+        vals = rng.integers(0, P, size=1 << log_m, dtype=np.uint64).astype(np.uint32)
+        vals[:8] = [0, 1, P - 1, P - 2, 2, P // 2, P // 2 + 1, 3]
+        try:
+            field_oracle.set_fieldhash_batch(False)
+            want = field_oracle.merkle_build(vals)
+            field_oracle.set_fieldhash_batch(True)
+            got = field_oracle.merkle_build(vals)
+        finally:
+            field_oracle.set_fieldhash_batch(True)
+        assert np.array_equal(got, want), log_m
+    try:
+        field_oracle.set_fieldhash_batch(False)
+        want = field_oracle.prove(11, 3, want_vectors=False)
+    finally:
+        field_oracle.set_fieldhash_batch(True)
+    got = field_oracle.prove(11, 3, want_vectors=False)
+    assert got.proof == want.proof and got.state == want.state
+
+
 # ---- GPU ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_m", [0, 1, 4, 9, 12, 16, 19])
@@ -84,7 +109,7 @@ def test_fieldhash_full_size_properties(zk):
 
 @pytest.mark.gpu
 def test_fieldhash_prover_matches_oracle_domain_2e21(zk, field_oracle):
-    """The largest full-proof comparison the oracle's plain-residue hash affords (12.6 M hashes: ~15 s on 16 cores)."""
+    """A mid-size full-proof comparison (12.6 M hashes)."""
     log_n, log_b = 18, 3
     want = field_oracle.prove(log_n, log_b, want_vectors=False)
     with zk.Context(log_n, log_b, hash="field") as ctx:
@@ -95,18 +120,28 @@ def test_fieldhash_prover_matches_oracle_domain_2e21(zk, field_oracle):
 
 @pytest.mark.gpu
 def test_config5_fieldhash_full_prover_domain_2e24(zk, field_oracle):
-    """BASELINE.json configs[4] at its stated size: domain 2^24, Merkle hash = the field-native hash.
-    The oracle's hash is too slow for 10^8 nodes, so at this size: the proof verifies; proving is idempotent; the
-    committed f_eval layer equals the SHA-256 prover's (the hash does not touch the arithmetic); for the f_eval and
-    cp trees the 4096 nodes of depth 12 reduce to the root with the ORACLE's hash and sampled depth-12 subtrees
-    (4096 leaves each, every throughput-kernel level) equal the oracle's; openings recompute the root."""
+    """BASELINE.json configs[4] at its stated size: domain 2^24, Merkle hash = the field-native hash, compared with the
+    oracle as configs[2] is (test_config3_*): every proof byte, the final channel state, all 23 Merkle roots and every
+    challenge (round 4: the oracle hashes eight nodes at a time, 10^8 hashes in seconds; rounds 1-3 could only sample).
+    Kept from the sampled version: the proof verifies; proving is idempotent; the committed f_eval layer equals the
+    SHA-256 prover's (the hash does not touch the arithmetic); for the f_eval and cp trees the 4096 nodes of depth 12
+    reduce to the root with the oracle's SCALAR node hash and sampled depth-12 subtrees equal the oracle's; openings
+    recompute the root."""
     log_n, log_b = 21, 3
     N = 1 << (log_n + log_b)
     trace = zk.trace_fibsq((1 << log_n) - 1)
+    want = field_oracle.prove(log_n, log_b, want_vectors=False, want_roots=True)
+    assert want.rc == 0
     with zk.Context(log_n, log_b, hash="field") as ctx:
         proof = ctx.prove(trace)
         proof.verify()
         info = ctx.last_transcript()
+        for t in range(log_n + 2):
+            assert bytes(info.roots[t]) == bytes(want.roots[t]), f"root of tree {t}"
+        assert list(info.alpha_raw) == want.alpha_raw and list(info.beta_raw)[:log_n] == want.beta_raw
+        assert info.free_term == want.free_term and info.query_raw == want.query_raw
+        assert proof.data == want.proof, "field-hash proof bytes differ from the CPU oracle at domain 2^24"
+        assert proof.state == want.state
         again = ctx.prove()
         assert again.data == proof.data and again.state == proof.state
         f_digest = hashlib.sha256(ctx.layer_read(0).tobytes()).hexdigest()

@@ -49,10 +49,58 @@ def test_shard_world1_rccl_matches_oracle(zk, orc, log_n, log_b, opts):
         assert bytes(info.roots[t]) == bytes(want.roots[t]), t
     assert list(info.beta_raw)[:log_n] == want.beta_raw and info.free_term == want.free_term
     assert st["native_rccl"] == 1 and st["sent_bytes"] == 0 and st["sharded_layers"] >= 1
+    assert st["selftest_ok"] == 1                            # zk_shard_create's known-pattern exchange through RCCL
     if "overlap_min_log" in opts:
         assert st["chunked_layers"] >= 2
+        assert st["communicators"] == 2                      # the chunked exchanges run on their own communicator
+    else:
+        assert st["communicators"] == (2 if zk.shard_plan(1, log_n, log_b, force_collectives=True, **opts)["chunked_mask"] else 1)
     assert (pref.data, pref.state) == orc.prove_prefixed(b"prefix", log_n, log_b)
     proof.verify(strict=True)
+
+
+@pytest.mark.parametrize("opts,want_comms", [
+    (dict(), 2),                                  # chunked exchange on its own communicator (the default)
+    (dict(single_communicator=True), 1),          # ... sharing the main one, ordered by the collective events alone
+    (dict(plain_collectives=True), 1),            # the fall-back rung of bench.py: nothing in chunks, roots by all-gather
+    (dict(single_build_stream=True), 2),
+])
+def test_shard_options_profiling_and_self_test(zk, orc, opts, want_comms):
+    """zk_shard_options' operational fields (round 4: they replace the ZK_SHARD_* environment switches), the exchange
+    timing of zk_shard_set_profiling and zk_shard_self_test, one rank over RCCL; the proof bytes never change."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log_n, log_b = 14, 3
+    want = orc.prove(log_n, log_b, want_vectors=False)
+    with zk.ShardContext(log_n, log_b, 0, 1, zk.shard_unique_id(), force_collectives=True, min_layer_log=1, min_chunk_log=6,
+                         overlap_min_log=10, timeout_s=15.0, **opts) as sp:
+        sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        proof = sp.prove()
+        st0 = sp.stats()
+        sp.set_profiling(True)
+        again = sp.prove()
+        st1 = sp.stats()
+        sp.self_test()
+        sp.set_profiling(False)
+        last = sp.prove()
+        root = sp.lde_commit()
+    assert proof.data == want.proof == again.data == last.data and proof.state == want.state
+    assert st0["communicators"] == want_comms and st0["selftest_ok"] == 1 and st0["selftest_ms"] > 0
+    plain = bool(opts.get("plain_collectives"))
+    assert (st0["chunked_layers"] == 0) == plain and st0["root_board"] == (0 if plain else 1)
+    assert st0["exchange_ms"] == 0 and st0["exchanges"] == 0                     # profiling off: nothing timed
+    assert st1["exchanges"] >= st1["sharded_layers"] + 1 and st1["exchange_ms"] > 0 and st1["tail_ms"] > 0
+    assert 0 <= st1["exposed_exchange_ms"] <= st1["exchange_ms"] * 1.5 + 1.0
+    assert root == bytes(orc.prove(log_n, log_b, want_vectors=False, want_roots=True).roots[0])
+
+
+def test_shard_self_test_catches_a_transport_that_loses_data(zk):
+    """A transport whose all-to-all reports success without moving anything: zk_shard_create must fail in its self-test,
+    naming the exchange, instead of producing proofs from a zero-filled receive buffer."""
+    from zkstark_amd import _lib
+    lazy = _lib.ShardTransport(None, _lib.ALL_TO_ALL_FN(lambda *a: 0), _lib.ALL_GATHER_FN(lambda *a: 0))
+    with pytest.raises(zk.ZkError) as e:
+        zk.ShardContext(12, 3, 0, 1, os.urandom(128), transport=lazy, force_collectives=True, min_layer_log=1, min_chunk_log=5)
+    assert e.value.code == -2 and "self-test" in str(e.value)
 
 
 @pytest.mark.parametrize("hash_name,queries", [("field", 1), ("sha256", 3), ("field", 4)])

@@ -1,4 +1,6 @@
-"""The sharded prover on real hardware: HipBackend (C-ABI device primitives on torch tensors).
+"""The torch.distributed MIRROR of the sharded prover (tests/sharded_mirror.py: test infrastructure, NOT the product --
+the product is the native zk_shard_* prover, covered by tests/test_gpu_shard_native.py) on real hardware:
+HipBackend (C-ABI device primitives on torch tensors).
 world = 1 in-process, and world = 2 as two processes sharing the one GPU of the test box with the
 collectives staged through gloo (RCCL needs one GPU per rank; the exchange logic is the same)."""
 import os
@@ -14,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("log_n,log_b", [(10, 3), (13, 3)])
 def test_sharded_world1_matches_oracle(zk, orc, log_n, log_b):
-    from zkstark_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sharded_mirror as sharded
     want = orc.prove(log_n, log_b, want_vectors=False)
     be = sharded.HipBackend(0)
     sp = sharded.ShardedProver(log_n, log_b, sharded.LocalComm(), be, min_chunk_log=4)
@@ -27,8 +30,10 @@ def test_sharded_world1_matches_oracle(zk, orc, log_n, log_b):
 
 def _worker(rank, world, port, log_n, log_b, q, lat):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     if lat:
-        os.environ["ZK_MERKLE_LATENCY_LOG"] = str(lat)     # chunk builds hand over at this depth (tuning knob)
+        from zkstark_amd import _lib
+        _lib.check(_lib.load().zk_dev_set_merkle_latency_log(lat))     # chunk builds hand over at this depth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -36,7 +41,8 @@ def _worker(rank, world, port, log_n, log_b, q, lat):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import zkstark_amd as zk
-        from zkstark_amd import sharded
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import sharded_mirror as sharded
         torch.cuda.set_device(0)
         be = sharded.HipBackend(0)
         sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(staged=True), be, min_chunk_log=6, overlap_min_log=8)
@@ -74,7 +80,8 @@ def test_shard_domain_primitives_match_definition(zk, orc, log_n, log_b, rank_ex
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from sharded_testlib import OracleBackend
-    from zkstark_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sharded_mirror as sharded
     P = 3221225473
     hglob = pow(5, (P - 1) >> (log_n + 3), P)
     shift = 5 * pow(hglob, rank_exp, P) % P
@@ -116,7 +123,8 @@ def _nccl_worker(port, log_n, log_b, q):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         import zkstark_amd as zk
-        from zkstark_amd import sharded
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import sharded_mirror as sharded
         be = sharded.HipBackend(0)
         sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(force=True), be, min_chunk_log=6, overlap_min_log=8)
         sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
@@ -153,7 +161,8 @@ def _config4_worker(rank, world, port, log_n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import zkstark_amd as zk
-        from zkstark_amd import sharded
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import sharded_mirror as sharded
         torch.cuda.set_device(0)
         be = sharded.HipBackend(0)
         sp = sharded.ShardedProver(log_n, 3, sharded.Comm(staged=True), be)
@@ -168,7 +177,7 @@ def _config4_worker(rank, world, port, log_n, q):
 
 
 def test_config4_sharded_lde_and_transpose_domain_2e26(zk, config4_expected):
-    """configs[3] through the torch.distributed mirror (zkstark_amd/sharded.py): domain 2^26 evaluated by 2 ranks
+    """configs[3] through the torch.distributed mirror (tests/sharded_mirror.py): domain 2^26 evaluated by 2 ranks
     (each its cosets, no communication), all-to-all transpose to natural order, subtree commitment; the root and
     the shards equal the CPU oracle's (orc.lde + orc.merkle_build)."""
     import torch.multiprocessing as mp

@@ -1,5 +1,6 @@
 """The N > 1 path on CPU: world_size-2 and -4 gloo process groups run the sharded prover
-(zkstark_amd/sharded.py: the product's protocol and exchange logic) with the CPU test double as
+(tests/sharded_mirror.py: the torch.distributed MIRROR of the native zk_shard_* protocol; the native prover itself
+needs a GPU for every kernel and therefore has NO CPU test -- its tests are tests/test_gpu_shard_native.py) with the CPU test double as
 compute backend; the proof bytes must equal the single-process oracle's.  No GPU."""
 import hashlib
 import os
@@ -32,7 +33,7 @@ def _worker(rank, world, port, log_n, log_b, min_chunk_log, q, min_layer_log=Non
     try:
         import oracle
         from sharded_testlib import OracleBackend
-        from zkstark_amd import sharded
+        import sharded_mirror as sharded
         be = OracleBackend()
         sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(), be, min_chunk_log=min_chunk_log, min_layer_log=min_layer_log,
                                    use_board=use_board)
@@ -107,7 +108,7 @@ def _chunk_worker(rank, world, port, log_n, log_b, lists, q):
     try:
         import oracle
         from sharded_testlib import ChunkingOracleBackend
-        from zkstark_amd import sharded
+        import sharded_mirror as sharded
         be = ChunkingOracleBackend()
         sp = sharded.ShardedProver(log_n, log_b, sharded.Comm(lists=lists), be, min_chunk_log=3, overlap_min_log=3)
         sp.trace_upload(oracle.trace_fibsq((1 << log_n) - 1))
@@ -141,7 +142,8 @@ def test_chunked_exchange_multirank(orc, world, log_n, log_b, lists):
 
 
 def test_sharded_requires_world_dividing_blowup(zk):
-    from zkstark_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sharded_mirror as sharded
 
     class FakeComm:
         rank, world = 0, 4
@@ -151,7 +153,8 @@ def test_sharded_requires_world_dividing_blowup(zk):
 
 def test_path_nodes_and_host_top(orc):
     """merkle.rs:54-71 index walk and the host top-of-tree agree with the oracle's full tree."""
-    from zkstark_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sharded_mirror as sharded
     import numpy as np
     vals = np.arange(16, dtype=np.uint32) * 7 + 1
     nodes = orc.merkle_build(vals)

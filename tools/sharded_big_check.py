@@ -7,7 +7,7 @@ import torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 import zkstark_amd as zk
-from zkstark_amd import sharded
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import sharded_mirror as sharded   # the torch.distributed mirror (test infrastructure)
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 a = zk.trace_fibsq((1 << log_n) - 1)
 be = sharded.HipBackend(0)

@@ -1,10 +1,10 @@
 """Times the sharded orchestration (world = 1, no collectives) against the one-call C++ prover at the
-same size: the difference is Python + unfused-kernel overhead of zkstark_amd/sharded.py."""
+same size: the difference is Python + unfused-kernel overhead of tests/sharded_mirror.py."""
 import sys, time
 sys.path.insert(0, '.')
 import torch
 import zkstark_amd as zk
-from zkstark_amd import sharded
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import sharded_mirror as sharded   # the torch.distributed mirror (test infrastructure)
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 a = zk.trace_fibsq((1 << log_n) - 1)
 be = sharded.HipBackend(0)

@@ -2,7 +2,7 @@ import sys, time, cProfile, pstats
 sys.path.insert(0, '.')
 import torch
 import zkstark_amd as zk
-from zkstark_amd import sharded
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import sharded_mirror as sharded   # the torch.distributed mirror (test infrastructure)
 log_n = 21
 a = zk.trace_fibsq((1 << log_n) - 1)
 be = sharded.HipBackend(0)

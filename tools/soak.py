@@ -35,7 +35,7 @@ def mk_batch():
     return b
 
 def mk_sharded():
-    from zkstark_amd import sharded
+    import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import sharded_mirror as sharded
     sp = sharded.ShardedProver(17, 3, sharded.LocalComm(), sharded.HipBackend(0), min_chunk_log=8)
     sp.trace_upload(zk.trace_fibsq((1 << 17) - 1))
     return sp

@@ -42,12 +42,15 @@ class ShardTransport(C.Structure):
 
 class ShardOptions(C.Structure):
     _fields_ = [("min_layer_log", C.c_uint32), ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32),
-                ("force_collectives", C.c_int), ("no_root_board", C.c_int)]
+                ("force_collectives", C.c_int), ("no_root_board", C.c_int), ("plain_collectives", C.c_int),
+                ("single_build_stream", C.c_int), ("single_communicator", C.c_int), ("reserved", C.c_int), ("timeout_s", C.c_double)]
 
 
 class ShardStats(C.Structure):
     _fields_ = [("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
-                ("rccl_nranks", C.c_uint32), ("reserved", C.c_uint32), ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double)]
+                ("rccl_nranks", C.c_uint32), ("communicators", C.c_uint32), ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double),
+                ("exchange_ms", C.c_double), ("exposed_exchange_ms", C.c_double), ("tail_ms", C.c_double), ("selftest_ms", C.c_double),
+                ("exchanges", C.c_uint32), ("selftest_ok", C.c_uint32)]
 
 
 class ChainProbe(C.Structure):
@@ -73,6 +76,7 @@ SYMBOLS = {
     "zk_version": (_cp, []),
     "zk_build_hash": (_cp, []),
     "zk_host_hash_mode": (C.c_int, []),
+    "zk_host_set_hash_mode": (C.c_int, [C.c_int]),
     "zk_field_add": (_u32, [_u32, _u32]),
     "zk_field_sub": (_u32, [_u32, _u32]),
     "zk_field_mul": (_u32, [_u32, _u32]),
@@ -127,6 +131,8 @@ SYMBOLS = {
     "zk_batch_size": (_sz, [_vp]),
     "zk_batch_set_queries": (_int, [_vp, _u32]),
     "zk_batch_set_hash": (_int, [_vp, _int]),
+    "zk_batch_set_host_levels": (_int, [_vp, _int]),
+    "zk_batch_set_threads": (_int, [_vp, _u32]),
     "zk_batch_device_bytes": (_sz, [_vp]),
     "zk_batch_set_traces": (_int, [_vp, _vp]),
     "zk_batch_gen_fibsq": (_int, [_vp, _vp, _vp]),
@@ -134,6 +140,7 @@ SYMBOLS = {
     "zk_batch_prove": (_int, [_vp, _vp, _sz, _vp]),
     "zk_committer_create": (_int, [_int, C.POINTER(_vp)]),
     "zk_committer_destroy": (_int, [_vp]),
+    "zk_committer_set_top": (_int, [_vp, _u32]),
     "zk_dev_merkle_commit": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _int, _vp]),
     "zk_dev_merkle_commit_finish": (_int, [_vp, _vp, _u32, _u32, _vp, _int, _vp]),
     "zk_dev_merkle_finish": (_int, [_vp, _u32, _u32, _vp, _int]),
@@ -173,6 +180,8 @@ SYMBOLS = {
     "zk_shard_set_hash": (_int, [_vp, _int]),
     "zk_shard_set_queries": (_int, [_vp, _u32]),
     "zk_shard_inject_failure": (_int, [_vp, _int]),
+    "zk_shard_self_test": (_int, [_vp]),
+    "zk_shard_set_profiling": (_int, [_vp, _int]),
     "zk_shard_last_transcript": (_int, [_vp, C.POINTER(TranscriptInfo)]),
     "zk_shard_layer_read": (_int, [_vp, _u32, _sz, _sz, _vp]),
     "zk_shard_get_stats": (_int, [_vp, C.POINTER(ShardStats)]),
@@ -181,6 +190,7 @@ SYMBOLS = {
     "zk_dev_kernel_stats": (_int, [_vp, _sz, _int]),
     "zk_dev_merkle_build": (_int, [_vp, _u32, _vp, _vp]),
     "zk_dev_merkle_node": (_int, [_vp, _sz, _vp, _vp]),
+    "zk_dev_set_merkle_latency_log": (_int, [_u32]),
 }
 
 _lib = None

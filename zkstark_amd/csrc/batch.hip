@@ -228,14 +228,13 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
     HIPCHK_B(hipHostGetDevicePointer((void**)&b->d_stage, b->h_stage, 0));
     b->h_segs = reinterpret_cast<ScatterSeg*>(b->h_stage + b->stage_words);
     b->d_segs = reinterpret_cast<ScatterSeg*>(b->d_stage + b->stage_words);
-    b->host_levels = host_sha_available() && !(getenv("ZK_HOST_TOP_LOG") && atoi(getenv("ZK_HOST_TOP_LOG")) == 0);
+    b->host_levels = host_sha_available();               // zk_batch_set_host_levels(b, 0) keeps every level on the device
     HIPCHK_B(hipStreamSynchronize(b->stream));
 #undef HIPCHK_B
     b->first.assign(b->batch, 0);
     b->last.assign(b->batch, 0);
     unsigned hw = std::thread::hardware_concurrency();
     unsigned want = hw > 1 ? (hw - 1 < 15 ? hw - 1 : 15) : 0;
-    if (const char* e = getenv("ZK_BATCH_THREADS")) want = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) - 1 : 0;
     if (b->batch < 2) want = 0;
     b->pool = new (std::nothrow) Pool(want);
     if (!b->pool) return bail(fail(ZK_ERR_NOMEM, "out of host memory"));
@@ -244,6 +243,22 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
 }
 
 size_t zk_batch_size(const zk_batch* b) { return b ? b->batch : 0; }
+int zk_batch_set_host_levels(zk_batch* b, int on) {
+    if (!b) return fail(ZK_ERR_INVALID, "null batch");
+    if (b->single) return zk_ctx_set_host_levels(b->single, on && host_sha_available() ? 8 : 0, on && host_sha_available() ? 9 : 0);
+    b->host_levels = on != 0 && host_sha_available();
+    return ZK_OK;
+}
+int zk_batch_set_threads(zk_batch* b, uint32_t threads) {
+    if (!b) return fail(ZK_ERR_INVALID, "null batch");
+    if (threads < 1 || threads > 64) return fail(ZK_ERR_INVALID, "zk_batch_set_threads: need 1 <= threads <= 64");
+    if (b->single || !b->pool || b->pool->workers() == threads - 1) return ZK_OK;
+    Pool* np = new (std::nothrow) Pool(threads - 1);
+    if (!np) return fail(ZK_ERR_NOMEM, "out of host memory");
+    delete b->pool;
+    b->pool = np;
+    return ZK_OK;
+}
 int zk_batch_set_queries(zk_batch* b, uint32_t n_queries) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
     if (n_queries < 1 || n_queries > 16) return fail(ZK_ERR_INVALID, "zk_batch_set_queries: need 1 <= n_queries <= 16");

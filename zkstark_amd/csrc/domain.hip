@@ -148,8 +148,9 @@ int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t
     // iNTT_g of (a_0 .. a_{n-2}, 0): natural -> digit-reversed, unscaled (1/n is folded into the next pass)
     int rc = run_dif(d_trace, d_coef, d->log_n, d->plan, d->Hinv.view(), d->L, 0, s, prof, batch, ts, cs);
     if (rc) return rc;
-    // virtual-point correction, coset shift and 1/n (coef_prepare): as its own sweep d_coef[0..n) -> d_coef[n..2n), or,
-    // for small n (latency-bound: every launch counts), applied by the first LDE pass as it loads the coefficients
+    // virtual-point correction, coset shift and 1/n (coef_prepare): applied by the first LDE pass, which loads the
+    // coefficient blocks of its tile once, prepares them and keeps them in LDS for the B columns that use them; only
+    // shapes the register-radix kernel does not take run the separate sweep d_coef[0..n) -> d_coef[n..2n)
     uint32_t* d_prep = d_coef + d->n;
     CoefPrepArgs pa{};
     pa.log_n = d->log_n; pa.log_b = d->log_b;
@@ -167,7 +168,7 @@ int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t
         if (q == (int)d->plan.nd - 1) {
             if (a.logC < d->log_b) a.logC = d->log_b;
             a.src_stride = cs;
-            const bool fuse = d->log_n <= kFusePrepMaxLogN && ntt_fast_ok(a, NTT_DIT_LDE);
+            const bool fuse = ntt_fast_ok(a, NTT_DIT_LDE);
             if (fuse) {
                 a.src = d_coef;                                   // raw DIF output: prepared at the load
                 a.prep = 1; a.prep_log_n = d->log_n; a.prep_log_b = d->log_b; a.prep_ninv_mont = d->ninv_mont;
@@ -242,7 +243,7 @@ int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t lo
 
 // Waits until the mailbox carries the sequence number of the last commit launch (polling host-coherent
 // memory: no blit kernel, no stream synchronisation on the commit -> challenge path).
-int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*), void* poll_user) {
+int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*), void* poll_user, double timeout_s) {
     auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
@@ -260,8 +261,8 @@ int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*pol
                 return fail(ZK_ERR_HIP, "merkle digests were never posted (stream drained)");
             if (q != hipSuccess && q != hipErrorNotReady)
                 return fail(ZK_ERR_HIP, "device error while waiting for merkle digests: %s", hipGetErrorString(q));
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-                return fail(ZK_ERR_HIP, "timed out waiting for merkle digests");
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                return fail(ZK_ERR_HIP, "timed out after %.0f s waiting for merkle digests", timeout_s);
         }
     }
     return ZK_OK;

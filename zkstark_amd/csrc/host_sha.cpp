@@ -1,6 +1,8 @@
 // host_sha.cpp -- see host_sha.hpp.  Host-only translation unit (nothing here is device code).
 #include "host_sha.hpp"
 
+#include <atomic>
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
 #include <stdlib.h>
@@ -24,17 +26,21 @@ const uint32_t IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x51
 
 // K[t] + W[t] of the second block of a 64-byte message (0x80, zeros, length 512): its schedule is constant
 alignas(16) uint32_t PADKW[64];
-bool g_have_sha = false, g_cpu_has_sha = false;
-bool g_have_x16 = false, g_cpu_has_x16 = false;       // AVX-512F: sixteen nodes per instruction stream (below)
+// What the CPU can do (set once at load) and what is in use.  The setters (zk_host_set_hash_mode) may run while pool
+// threads hash, so the flags in use are atomics (relaxed: either setting gives the same digests).
+bool g_cpu_has_sha = false, g_cpu_has_x16 = false;    // x16 = AVX-512F: sixteen nodes per instruction stream (below)
+std::atomic<bool> g_have_sha{false}, g_have_x16{false};
+std::atomic<bool> g_want_x16{true};                   // host_sha_use_wide(false) survives a later host_sha_use_extensions(true)
 
 inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
 struct Init {
     Init() {
         __builtin_cpu_init();
-        g_cpu_has_sha = g_have_sha = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
-        g_cpu_has_x16 = g_have_x16 = g_cpu_has_sha && __builtin_cpu_supports("avx512f");
-        if (const char* e = getenv("ZK_HOST_SHA_WIDE")) g_have_x16 = g_have_x16 && atoi(e) != 0;      // A/B switch
+        g_cpu_has_sha = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+        g_cpu_has_x16 = g_cpu_has_sha && __builtin_cpu_supports("avx512f");
+        g_have_sha = g_cpu_has_sha;
+        g_have_x16 = g_cpu_has_x16;
         uint32_t w[64] = {0x80000000u};
         w[15] = 512u;
         for (int t = 16; t < 64; ++t) {
@@ -314,9 +320,15 @@ void compress_generic(uint32_t st[8], const uint32_t blk[16]) {
 }  // namespace
 
 bool host_sha_available() { return g_have_sha; }
-void host_sha_use_extensions(bool on) { g_have_sha = on && g_cpu_has_sha; g_have_x16 = on && g_cpu_has_x16; }
+void host_sha_use_extensions(bool on) {
+    g_have_sha = on && g_cpu_has_sha;
+    g_have_x16 = on && g_cpu_has_x16 && g_want_x16.load(std::memory_order_relaxed);
+}
 bool host_sha_wide_available() { return g_have_x16; }
-void host_sha_use_wide(bool on) { g_have_x16 = on && g_have_sha && g_cpu_has_x16; }
+void host_sha_use_wide(bool on) {
+    g_want_x16 = on;
+    g_have_x16 = on && g_have_sha.load(std::memory_order_relaxed) && g_cpu_has_x16;
+}
 
 void host_sha_compress(uint32_t state[8], const uint32_t block[16]) {
     if (g_have_sha) compress_ni(state, block);

@@ -36,9 +36,6 @@ constexpr uint32_t kMaxHostLog = 10;                         // host_top, host_t
 constexpr size_t kMailValsOff = kMailDigests + ((size_t)8 << kMaxHostLog);   // after the digests of depth host_top
 constexpr size_t kMailWords = kMailValsOff + ((size_t)2 << kMaxHostLog);     // values of the layer that feeds the host tail
 constexpr uint32_t kMaxRadixLog = 8;
-// up to this trace size the coefficient preparation is fused into the first LDE pass (each coefficient is then
-// prepared by the B columns that load it: B-fold redundant arithmetic, one launch and one sweep less)
-constexpr uint32_t kFusePrepMaxLogN = 18;
 
 // Sizes a proof can have: shared by zk_ctx_create and zk_batch_create so that everything the provers accept is something
 // the verifier (transcript.hpp: log_n >= 2) can check.  n = 8 is degenerate: g^4 = -1 cancels the leading terms of
@@ -118,7 +115,8 @@ int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t lo
 // Waits until *flag (host-mapped memory written by a commit launch on `stream`) equals `want`.  poll (optional) is
 // called every few thousand spins; a non-zero return ends the wait with that code (the sharded prover looks for a
 // peer that has left the proof: the launch may sit behind a collective that will never complete).
-int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*) = nullptr, void* poll_user = nullptr);
+// timeout_s: how long to wait for the flag (the sharded prover passes its own bound: the launch may sit behind an exchange)
+int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*) = nullptr, void* poll_user = nullptr, double timeout_s = 30.0);
 double now_us();
 // merkle.rs:54-71: node indices of the authentication path of `leaf` in a tree of m leaves
 void path_nodes(size_t m, size_t leaf, std::vector<size_t>& out);

@@ -760,17 +760,30 @@ static hipError_t ensure_fieldhash_consts() {
 // Throughput phase: subtree launches (k <= 4 levels each) while the level has more than 2^18 nodes,
 // i.e. while there are more than ~4 waves per SIMD to keep busy.  Latency phase: workgroup launches
 // of up to 10 levels each.
-constexpr uint32_t kMerkleLatencyLogDefault = 17;   // measured flat optimum 16..18 (profiles/README.md)
-static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
-    const char* e = getenv(name);
-    if (!e) return dflt;
-    const uint32_t x = (uint32_t)atoi(e);
-    return (x < lo || x > hi) ? dflt : x;
+// Build-time constants (ZK_BUILD_DEFS="-DZK_MERKLE_MAX_K=3" to A/B them; profiles/r03_ab_max_k.txt, r03_config2_switches.txt):
+// levels per subtree launch, and the level size at which the throughput phase hands over to the latency phase (measured
+// flat optimum 2^16 .. 2^18 nodes).  The hand-over depth can also be moved at run time with zk_dev_set_merkle_latency_log
+// (include/zkstark_amd.h: tests use it to drive small trees through the chunked build).
+#ifndef ZK_MERKLE_MAX_K
+#define ZK_MERKLE_MAX_K 4
+#endif
+#ifndef ZK_MERKLE_LATENCY_LOG
+#define ZK_MERKLE_LATENCY_LOG 17
+#endif
+#ifndef ZK_MERKLE_CHUNK_K
+#define ZK_MERKLE_CHUNK_K 3
+#endif
+static_assert(ZK_MERKLE_MAX_K >= 1 && ZK_MERKLE_MAX_K <= (int)kMerkleMaxK && ZK_MERKLE_CHUNK_K >= 1 && ZK_MERKLE_CHUNK_K <= (int)kMerkleMaxK, "levels per launch");
+static_assert(ZK_MERKLE_LATENCY_LOG >= 12 && ZK_MERKLE_LATENCY_LOG <= 24, "latency switch");
+static uint32_t g_merkle_latency_log = ZK_MERKLE_LATENCY_LOG;
+static constexpr uint32_t merkle_max_k() { return ZK_MERKLE_MAX_K; }
+static uint32_t merkle_latency_log() { return __atomic_load_n(&g_merkle_latency_log, __ATOMIC_RELAXED); }
+bool set_merkle_latency_log(uint32_t v) {
+    if (v == 0) v = ZK_MERKLE_LATENCY_LOG;
+    if (v < 12 || v > 24) return false;
+    __atomic_store_n(&g_merkle_latency_log, v, __ATOMIC_RELAXED);
+    return true;
 }
-// Tuning switches (environment, read once).  ZK_MERKLE_MAX_K: levels per subtree launch.
-uint32_t ntt_small_tile_max_log() { static const uint32_t v = env_u32("ZK_NTT_SMALL_MAX_LOG", 20, 12, 30); return v; }
-static uint32_t merkle_max_k() { static const uint32_t v = env_u32("ZK_MERKLE_MAX_K", kMerkleMaxK, 1, kMerkleMaxK); return v; }
-static uint32_t merkle_latency_log() { static const uint32_t v = env_u32("ZK_MERKLE_LATENCY_LOG", kMerkleLatencyLogDefault, 12, 24); return v; }
 
 // Builds the levels of a heap over 2^log_m leaves that lie above the aligned leaf range
 // [chunk << log_sub, (chunk + 1) << log_sub), from the leaves (leaf_mode) or from the nodes already
@@ -864,7 +877,7 @@ hipError_t launch_merkle_build_interleaved(const uint32_t* recv, uint32_t log_pa
 // of five per CU) instead of 1 024 of 40 KiB that start and end together, so LDS frees up all through the launch and the
 // workgroups of the exchange kernel that runs beside it (rcclGenericKernel: 64 x 256 threads, 19.5 KiB of LDS each,
 // measured) find room on the CUs.  The hashing rate does not depend on k (profiles/r03_ab_max_k.txt).
-static uint32_t merkle_chunk_k() { static const uint32_t v = env_u32("ZK_MERKLE_CHUNK_K", 3, 1, kMerkleMaxK); return v; }
+static constexpr uint32_t merkle_chunk_k() { return ZK_MERKLE_CHUNK_K; }
 static uint32_t chunk_handover_depth(uint32_t log_m, uint32_t log_chunks) {
     const uint32_t lat = merkle_latency_log();
     if (!(log_m > lat && lat >= log_chunks + 8)) return log_chunks;
@@ -1015,6 +1028,34 @@ hipError_t launch_interleave(const uint32_t* in, uint32_t* out, uint32_t log_par
     size_t total = (size_t)1 << (log_parts + log_cnt);
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     hipLaunchKernelGGL(interleave_kernel, dim3(blocks), dim3(256), 0, s, in, out, log_parts, log_cnt);
+    return hipGetLastError();
+}
+
+// ---- known-pattern exchange (self-test of the sharded prover's transport, shard.hip) ----------------------------
+__global__ void pattern_fill_kernel(uint32_t* dst, uint32_t rank, uint32_t log_per, uint32_t log_parts) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << (log_per + log_parts))) return;
+    dst[i] = shard_pattern(rank, (uint32_t)(i >> log_per), (uint32_t)(i & (((size_t)1 << log_per) - 1)));
+}
+__global__ void pattern_check_kernel(const uint32_t* src, uint32_t rank, uint32_t log_per, uint32_t log_parts, uint32_t log_chunks, uint32_t* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << (log_per + log_parts))) return;
+    const uint32_t log_cc = log_per - log_chunks;
+    const uint32_t u = (uint32_t)(i & (((size_t)1 << log_cc) - 1));
+    const uint32_t q = (uint32_t)(i >> log_cc) & ((1u << log_parts) - 1u), c = (uint32_t)(i >> (log_cc + log_parts));
+    if (src[i] != shard_pattern(q, rank, (c << log_cc) | u)) {
+        atomicAdd(&out[0], 1u);
+        atomicMin(&out[1], (uint32_t)i);
+    }
+}
+hipError_t launch_pattern_fill(uint32_t* dst, uint32_t rank, uint32_t log_per, uint32_t log_parts, hipStream_t s) {
+    const size_t total = (size_t)1 << (log_per + log_parts);
+    hipLaunchKernelGGL(pattern_fill_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, dst, rank, log_per, log_parts);
+    return hipGetLastError();
+}
+hipError_t launch_pattern_check(const uint32_t* src, uint32_t rank, uint32_t log_per, uint32_t log_parts, uint32_t log_chunks, uint32_t* out, hipStream_t s) {
+    const size_t total = (size_t)1 << (log_per + log_parts);
+    hipLaunchKernelGGL(pattern_check_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, src, rank, log_per, log_parts, log_chunks, out);
     return hipGetLastError();
 }
 

@@ -78,12 +78,22 @@ enum NttMode : uint32_t {
 };
 
 // Workgroup tile of an NTT pass, in words: 8192 for big transforms (long row segments: HBM traffic 1.00-1.03 x the
-// algorithmic bytes), 2048 for passes over <= 2^20 words (latency-bound: 4 x the workgroups, a quarter of the elements
-// per thread).  At 2^21 the small tile was 12 % faster but fetched 2 x the bytes (64-byte row segments at radix 128,
-// PMC FETCH_SIZE), so the switch sits below that size.
-constexpr uint32_t kBigTileLog = 13, kSmallTileLog = 11;
-uint32_t ntt_small_tile_max_log();   // transforms of up to 2^this words use the small tile (kernels.hip; ZK_NTT_SMALL_MAX_LOG)
-inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total > ntt_small_tile_max_log() ? kBigTileLog : kSmallTileLog; }
+// algorithmic bytes), 4096 for passes over 2^21 .. 2^22 words (one workgroup per compute unit is a chain of latencies:
+// table look-up, loads, two register DFTs, stores; two lighter workgroups per unit overlap theirs, and a radix-128 row
+// segment is still a whole 128-byte line), 2048 for passes over <= 2^20 words (latency-bound: 4 x the workgroups, a
+// quarter of the elements per thread).  At 2^21 the 2048-word tile fetched 2 x the bytes (64-byte row segments at radix
+// 128, PMC FETCH_SIZE), so that size takes the middle tile.  Build-time constants (ZK_BUILD_DEFS to A/B them).
+#ifndef ZK_NTT_SMALL_MAX_LOG
+#define ZK_NTT_SMALL_MAX_LOG 20
+#endif
+#ifndef ZK_NTT_MID_MAX_LOG
+#define ZK_NTT_MID_MAX_LOG 22
+#endif
+constexpr uint32_t kBigTileLog = 13, kMidTileLog = 12, kSmallTileLog = 11;
+constexpr uint32_t kNttSmallTileMaxLog = ZK_NTT_SMALL_MAX_LOG, kNttMidTileMaxLog = ZK_NTT_MID_MAX_LOG;
+inline uint32_t ntt_tile_log(uint32_t log_total) {
+    return log_total <= kNttSmallTileMaxLog ? kSmallTileLog : log_total <= kNttMidTileMaxLog ? kMidTileLog : kBigTileLog;
+}
 
 struct NttPassArgs {
     const uint32_t* src;
@@ -99,7 +109,8 @@ struct NttPassArgs {
     uint32_t batch;       // 0 or 1 = a single transform
     size_t src_stride, dst_stride;
     // NTT_DIT_LDE with prep != 0: src is the raw DIF output U and the coefficient preparation of
-    // coef_prepare_kernel (CoefPrepArgs below) happens at the load; register-radix kernel only (ntt_fast_ok)
+    // coef_prepare_kernel (CoefPrepArgs below) happens inside the pass (once per coefficient, staged in LDS, when the
+    // blow-up is >= 2; at the load for B = 1); register-radix kernel only (ntt_fast_ok)
     uint32_t prep;
     uint32_t prep_log_n, prep_log_b, prep_ninv_mont, prep_nd;
     uint32_t prep_bits[kMaxDigits];
@@ -130,6 +141,19 @@ hipError_t launch_degree_check(const uint32_t* coef, uint32_t log_m, uint32_t nd
 // inv_xm1[i] = 1 / (shift h^i - 1) in Montgomery form, i < N (domain setup)
 hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s);
 hipError_t launch_interleave(const uint32_t* in, uint32_t* out, uint32_t log_parts, uint32_t log_cnt, hipStream_t s);
+
+// Known-pattern exchange of the sharded prover's self-test (shard.hip): word j of the piece rank `from` sends to rank `to`.
+inline __host__ __device__ uint32_t shard_pattern(uint32_t from, uint32_t to, uint32_t j) {
+    uint32_t x = ((from + 1u) * 0x9E3779B1u) ^ ((to + 1u) * 0x85EBCA6Bu) ^ (j * 0xC2B2AE35u + 0x27D4EB2Fu);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    return x;
+}
+// dst[p << log_per | j] = shard_pattern(rank, p, j), p < 2^log_parts
+hipError_t launch_pattern_fill(uint32_t* dst, uint32_t rank, uint32_t log_per, uint32_t log_parts, hipStream_t s);
+// Receive buffer of an all-to-all of those pieces: plain (log_chunks = 0): src[q << log_per | j] from rank q; in 2^log_chunks
+// chunks of cc = 2^(log_per - log_chunks) words: src[(c * parts + q) * cc + u] = word c * cc + u from rank q.
+// out[0] += words that are not shard_pattern(q, rank, j); out[1] = min over their indices (preset to 0xffffffff).
+hipError_t launch_pattern_check(const uint32_t* src, uint32_t rank, uint32_t log_per, uint32_t log_parts, uint32_t log_chunks, uint32_t* out, hipStream_t s);
 
 struct ComposeArgs {
     const uint32_t* f;        // N canonical evaluations of the trace polynomial
@@ -178,6 +202,9 @@ struct MailArgs {
 };
 hipError_t launch_merkle_build(const uint32_t* vals, uint32_t log_m, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                                const MailArgs& mail = MailArgs{}, int hash = 0);
+// level size (log2) at which a build switches from throughput launches to the workgroup-local latency phase;
+// 0 restores the build's default (zk_dev_set_merkle_latency_log); false: out of range (12 .. 24)
+bool set_merkle_latency_log(uint32_t v);
 struct ScatterSeg { uint64_t src, dst; uint32_t words, kind; };   // kind 0: into the trees array, 1: into the layers array
 hipError_t launch_scatter(const uint32_t* stage, const ScatterSeg* segs, uint32_t count, double words, uint32_t* trees, uint32_t* layers,
                           hipStream_t s, Profiler* prof = nullptr);

@@ -1,9 +1,9 @@
 // ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256).
 //
 // Same pass semantics as ntt_pass_kernel (kernels.hip): the array is [A][R][S], a workgroup owns
-// C columns x R rows.  The tile is R*C = 8192 words for large transforms and 2048 words for small
-// ones (NttPassArgs.tile_log: a 2^17-point transform is then 64 workgroups instead of 16, and every
-// thread handles 8 elements instead of 32 -- those passes are latency-bound, not bandwidth-bound).
+// C columns x R rows.  The tile is R*C = 8192 words for large transforms, 4096 for mid-size ones and
+// 2048 for small ones (NttPassArgs.tile_log; kernels.hpp: ntt_tile_log): passes over few words are
+// latency-bound, not bandwidth-bound, and want more, lighter workgroups per compute unit.
 // The R-point transform is a four-step inside the tile, R = Ra*Rb with Ra, Rb <= 16:
 //
 //   step 1  thread (tb, c): loads rows ta*Rb + tb, ta < Ra, straight into registers (lanes run
@@ -18,6 +18,14 @@
 // element per pass instead of ~9.  Passes whose inner stride S is smaller than C (the innermost
 // pass and the first LDE pass) stage their contiguous tile through LDS so that HBM accesses stay
 // full lines.  No bit reversal anywhere: register naming absorbs it.
+//
+// Addressing (round 4).  A pass is VALU-bound in this field (P > 2^31: every add / sub carries its
+// correction), so address arithmetic on the vector unit is paid for in butterflies: the ISA of round 3
+// spent 20 % of its VALU instructions on 64-bit element addresses (v_lshlrev_b64, v_lshl_add_u64, v_or).
+// Here every global access is a raw buffer access: (the workgroup's base in a buffer resource) + (uniform row
+// offset in an SGPR, computed on the scalar unit) + (32-bit byte offset of the lane in one VGPR, computed once
+// per thread): `buffer_load_dword v, v_off, s[rsrc], s_row offen`, no vector instruction per access.  (Plain
+// pointers do not get there: hipcc re-associates (base + row) + lane into a 64-bit vector add per access.)
 #include "kernels.hpp"
 
 #include "field.hpp"
@@ -77,26 +85,46 @@ __device__ __forceinline__ uint32_t pow_lookup(const PowTable& t, uint32_t e) {
     return mont_mul(t.hi[e >> t.lo_bits], t.lo[e & ((1u << t.lo_bits) - 1u)]);
 }
 
+// Raw buffer over [base, base + 4 GiB): word at base + lane_off + row_off (bytes; lane_off in a VGPR, row_off uniform).
+// An arrays of this library has at most 2^30 words, so every offset fits 32 bits; out-of-range reads return 0.
+using Rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Rsrc make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+}
+// A uniform value pinned to a scalar register where it is used.  Without this the register allocator parks long-lived
+// row offsets in VGPRs when SGPRs run short, and a buffer instruction whose scalar offset sits in a VGPR becomes a
+// waterfall loop (v_readfirstlane + compare + branch per access); readfirstlane of a value that already is in an SGPR folds away.
+__device__ __forceinline__ uint32_t in_sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t ld_b(Rsrc r, uint32_t lane_off, uint32_t row_off) { return __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0); }
+__device__ __forceinline__ void st_b(Rsrc r, uint32_t lane_off, uint32_t row_off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_off, row_off, 0); }
+
 constexpr int kThreads = 256;
 
 // MODE: NTT_DIF (inverse passes: DFT with w^-1, post-twiddle), NTT_DIT (forward passes: pre-twiddle),
-//       NTT_DIT_LDE (forward, S = B, source = n prepared coefficients, each feeding B columns).
+//       NTT_DIT_LDE (forward, S = B, source = n coefficients, each feeding B columns).
 // STAGED: the tile is one contiguous block of HBM (S < C): go through LDS for full-line accesses.
 // PREP (NTT_DIT_LDE only): the source is the raw DIF output U of the inverse transform and the
 //   interpolant's coefficient preparation (coef_prepare_kernel: virtual last trace point, coset shift,
-//   1/n) is applied to every value as it is loaded -- one launch and one pass over the coefficients less.
-template <uint32_t MODE, int LA, int LB, bool STAGED, int TILE_LOG, bool PREP>
+//   1/n) happens inside this pass -- one launch and one sweep over the coefficients less.
+//   PREP = 1: every value is prepared as a column loads it (B-fold redundant arithmetic; kept for B = 1, where
+//             nothing is redundant and the staging area below would be as large as the tile);
+//   PREP = 2: the tile's C / B coefficient blocks (contiguous in the source) are loaded ONCE, prepared and kept in
+//             LDS; the B columns of a block read them from there.  One preparation per coefficient at every size,
+//             so the separate sweep of round 3 (12 us at n = 2^21) is gone from every LDE.
+template <uint32_t MODE, int LA, int LB, bool STAGED, int TILE_LOG, int PREP>
 __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) {
     constexpr bool INV = (MODE == NTT_DIF);
+    constexpr bool LDE = (MODE == NTT_DIT_LDE);
     constexpr int LOGR = LA + LB, R = 1 << LOGR, RA = 1 << LA, RB = 1 << LB;
     constexpr int LOGC = TILE_LOG - LOGR, C = 1 << LOGC;
     constexpr uint32_t kTileLog = TILE_LOG;
-    constexpr int PITCH = STAGED || MODE == NTT_DIT_LDE ? C + 1 : C;
+    constexpr int PITCH = STAGED || LDE ? C + 1 : C;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     p.src += (size_t)blockIdx.y * p.src_stride;      // batch of independent transforms
     p.dst += (size_t)blockIdx.y * p.dst_stride;
     uint32_t* tile = smem;                    // R * PITCH
     uint32_t* twl = smem + R * PITCH;         // w_R^e, e < R
+    uint32_t* coef = twl + R;                 // PREP = 2: (C >> logB) blocks of R prepared coefficients, pitch R + 1
     const uint32_t tid = threadIdx.x;
     const uint32_t logS = p.logS;
     const uint32_t col0 = blockIdx.x << LOGC;
@@ -105,22 +133,50 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
 
     for (uint32_t e = tid; e < (uint32_t)R; e += kThreads) twl[e] = pow_lookup(p.tw, e << (p.L - LOGR));
 
-    // global word address of (column c of this tile, row t)
-    auto gaddr = [&](uint32_t c, uint32_t t) -> size_t {
-        uint32_t col = col0 + c, a = col >> logS, s = col & smask;
-        return ((size_t)a << (LOGR + logS)) | ((size_t)t << logS) | s;
-    };
+    // Non-staged tiles (S >= C) lie inside one block `a` of the [A][R][S] view: element (row t, column c) of the tile is
+    // word  (a << (LOGR + logS)) + (t << logS) + s0 + c.  The first and third terms are uniform (the workgroup's base),
+    // the row term is uniform per unrolled ta / kb (scalar add), the lane term (tb or ka, c) is one VGPR.
+    const uint32_t row_sh = logS + 2;                                        // log2 of the bytes between two rows
+    const size_t wg_word = ((size_t)(col0 >> logS) << (LOGR + logS)) + (col0 & smask);
+    const Rsrc srcb = make_rsrc(p.src + wg_word), dstb = make_rsrc(p.dst + wg_word);
+    // contiguous tiles (STAGED, and the destination of the first LDE pass)
+    const Rsrc tsrc = make_rsrc(p.src + ((size_t)blockIdx.x << kTileLog)), tdst = make_rsrc(p.dst + ((size_t)blockIdx.x << kTileLog));
 
-    if (STAGED && MODE != NTT_DIT_LDE) {
+    if (STAGED && !LDE) {
         // the tile is R*C consecutive words: copy in memory order, lanes along the fastest index
-        const size_t base = (size_t)blockIdx.x << kTileLog;
 #pragma unroll 4
         for (uint32_t l = tid; l < (uint32_t)(R * C); l += kThreads) {
             uint32_t s = l & smask, t = (l >> logS) & (R - 1), c = ((l >> (LOGR + logS)) << logS) | s;
-            tile[t * PITCH + c] = p.src[base + l];
+            tile[t * PITCH + c] = ld_b(tsrc, l << 2, 0);
         }
     }
-    __syncthreads();   // twl (and the staged tile) visible
+    if (LDE && PREP == 2) {
+        // the coefficient blocks col0 >> logB .. of this tile are (C >> logB) * R consecutive words of the source.
+        // Storage position (a, t) holds the coefficient of true index k = rev(a) | t << (log_n - LOGR): the slow storage
+        // digits of the digit-reversed DIF output are the LOW digits of k.
+        //   out = (U - U[n-1] g^(k+1)) * shift^k / n        (coef_prepare_kernel, kernels.hip)
+        const uint32_t logB = logS, log_n = p.prep_log_n, tsh = log_n - LOGR, n1 = (1u << log_n) - 1u;
+        const uint32_t a0 = col0 >> logB;
+        const Rsrc csrc = make_rsrc(p.src + ((size_t)a0 << LOGR));
+        const uint32_t c_top = p.src[n1];                          // U[n-1]
+        for (uint32_t l = tid; l < ((uint32_t)C >> logB) << LOGR; l += kThreads) {
+            const uint32_t ab = l >> LOGR, t = l & (R - 1), a = a0 + ab;
+            uint32_t ka = 0, rem = tsh, sh = 0;
+#pragma unroll                                                     // constant indices: the argument struct stays in SGPRs (no scratch copy)
+            for (uint32_t d = 0; d + 1 < (uint32_t)kMaxDigits; ++d) {
+                const uint32_t bits = d + 1 < p.prep_nd ? p.prep_bits[d] : 0u;
+                rem -= bits;
+                ka |= ((a >> rem) & ((1u << bits) - 1u)) << sh;
+                sh += bits;
+            }
+            const uint32_t k = ka | (t << tsh);
+            const uint32_t v = ld_b(csrc, l << 2, 0);
+            const uint32_t gk = pow_lookup(p.tw, ((k + 1u) & n1) << p.prep_log_b);
+            const uint32_t wk = mont_mul(pow_lookup(p.prep_wtab, k), p.prep_ninv_mont);
+            coef[ab * (R + 1) + t] = mont_mul(sub(v, mont_mul(c_top, gk)), wk);
+        }
+    }
+    __syncthreads();   // twl (and the staged tile / the prepared coefficients) visible
 
     // ---- step 1: Ra-point DFTs over ta (row stride Rb) ---------------------------------
 #pragma unroll 1
@@ -128,16 +184,20 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
         const uint32_t c = q & (C - 1), tb = q >> LOGC;
         const uint32_t s = (col0 + c) & smask;
         uint32_t x[RA];
-        if (MODE == NTT_DIT_LDE) {
-            const uint32_t a = (col0 + c) >> logS;                 // coefficient block; B columns share it
+        if (LDE && PREP == 2) {
+            const uint32_t* cb = coef + (c >> logS) * (R + 1) + tb;     // B columns share a block: broadcast reads, blocks in different banks
 #pragma unroll
-            for (int ta = 0; ta < RA; ++ta) x[ta] = p.src[((size_t)a << LOGR) | (uint32_t)(ta * RB + tb)];
-            if (PREP) {
-                // storage position (a, t) holds the coefficient of true index k = rev(a) | t << (log_n - LOGR):
-                // the slow storage digits of the digit-reversed DIF output are the LOW digits of k
+            for (int ta = 0; ta < RA; ++ta) x[ta] = cb[ta * RB];
+        } else if (LDE) {
+            const uint32_t a = (col0 + c) >> logS;                 // coefficient block; B columns share it
+            const Rsrc cb = make_rsrc(p.src);
+            const uint32_t off = (a << (LOGR + 2)) | (tb << 2);     // n <= 2^30 words: the byte offset fits 32 bits
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) x[ta] = ld_b(cb, off, (uint32_t)(ta * RB * 4));
+            if (PREP == 1) {
                 const uint32_t log_n = p.prep_log_n, tsh = log_n - LOGR;
                 uint32_t ka = 0, rem = tsh, sh = 0;
-#pragma unroll                                                     // constant indices: the argument struct stays in SGPRs (no scratch copy)
+#pragma unroll
                 for (uint32_t d = 0; d + 1 < (uint32_t)kMaxDigits; ++d) {
                     const uint32_t bits = d + 1 < p.prep_nd ? p.prep_bits[d] : 0u;
                     rem -= bits;
@@ -161,8 +221,9 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
 #pragma unroll
             for (int ta = 0; ta < RA; ++ta) x[ta] = tile[(ta * RB + tb) * PITCH + c];
         } else {
+            const uint32_t off = (tb << row_sh) + (c << 2);
 #pragma unroll
-            for (int ta = 0; ta < RA; ++ta) x[ta] = p.src[gaddr(c, ta * RB + tb)];
+            for (int ta = 0; ta < RA; ++ta) x[ta] = ld_b(srcb, off, in_sgpr((uint32_t)(ta * RB) << row_sh));
         }
         if (MODE != NTT_DIF && logS) {
             // pre-twiddle w_{RS}^(t*s), t = ta*Rb + tb: running product over ta
@@ -189,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
 
     // ---- step 2: Rb-point DFTs over tb (consecutive rows) ----------------------------------
     constexpr int IT2 = (RA * C + kThreads - 1) / kThreads;   // RA*C < kThreads (small tile, R = 256): half the threads idle here
+    constexpr bool TO_LDS = STAGED || LDE;                     // contiguous destination tile: stores go through LDS
     uint32_t keep[IT2][RB];   // staged stores wait until every thread has read the tile
 #pragma unroll
     for (int it = 0; it < IT2; ++it) {
@@ -216,12 +278,13 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
                 for (int i = 0; i < RB; ++i) y[i] = mont_mul(y[i], p.scale_mont);
             }
         }
-        if (!STAGED) {
+        if (!TO_LDS) {
+            const uint32_t off = (ka << row_sh) + (c << 2);
 #pragma unroll
-            for (int i = 0; i < RB; ++i) p.dst[gaddr(c, ka + RA * c_brev(i, LB))] = y[i];
+            for (int i = 0; i < RB; ++i) st_b(dstb, off, in_sgpr((uint32_t)(RA * c_brev(i, LB)) << row_sh), y[i]);
         }
     }
-    if (STAGED) {
+    if (TO_LDS) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
@@ -232,11 +295,10 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
             for (int i = 0; i < RB; ++i) tile[(ka + RA * c_brev(i, LB)) * PITCH + c] = keep[it][i];
         }
         __syncthreads();
-        const size_t base = (size_t)blockIdx.x << kTileLog;
 #pragma unroll 4
         for (uint32_t l = tid; l < (uint32_t)(R * C); l += kThreads) {
             uint32_t s = l & smask, t = (l >> logS) & (R - 1), c = ((l >> (LOGR + logS)) << logS) | s;
-            p.dst[base + l] = tile[t * PITCH + c];
+            st_b(tdst, l << 2, 0, tile[t * PITCH + c]);
         }
     }
 }
@@ -246,16 +308,26 @@ hipError_t launch3(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
     constexpr int R = 1 << (LA + LB), C = 1 << (TILE_LOG - LA - LB);
     size_t shmem = ((size_t)R * (C + 1) + R) * sizeof(uint32_t);
     const dim3 grid(blocks, a.batch ? a.batch : 1);
-    if (MODE == NTT_DIT_LDE && a.prep) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, MODE == NTT_DIT_LDE>), grid, dim3(kThreads), shmem, s, a);
-    else if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, false>), grid, dim3(kThreads), shmem, s, a);
-    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false, TILE_LOG, false>), grid, dim3(kThreads), shmem, s, a);
+    if (MODE == NTT_DIT_LDE && a.prep) {
+        if (a.logS >= 1) {
+            shmem += (size_t)(C >> a.logS) * (R + 1) * sizeof(uint32_t);
+            hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, MODE == NTT_DIT_LDE ? 2 : 0>), grid, dim3(kThreads), shmem, s, a);
+        } else {
+            hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, MODE == NTT_DIT_LDE ? 1 : 0>), grid, dim3(kThreads), shmem, s, a);
+        }
+    }
+    else if (staged) hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, true, TILE_LOG, 0>), grid, dim3(kThreads), shmem, s, a);
+    else hipLaunchKernelGGL((ntt_pass_fast_kernel<MODE, LA, LB, false, TILE_LOG, 0>), grid, dim3(kThreads), shmem, s, a);
     return hipGetLastError();
 }
 
 template <uint32_t MODE, int LA, int LB>
 hipError_t launch2(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
-    return a.tile_log == kSmallTileLog ? launch3<MODE, LA, LB, (int)kSmallTileLog>(a, staged, blocks, s)
-                                       : launch3<MODE, LA, LB, (int)kBigTileLog>(a, staged, blocks, s);
+    switch (a.tile_log) {
+        case kSmallTileLog: return launch3<MODE, LA, LB, (int)kSmallTileLog>(a, staged, blocks, s);
+        case kMidTileLog: return launch3<MODE, LA, LB, (int)kMidTileLog>(a, staged, blocks, s);
+        default: return launch3<MODE, LA, LB, (int)kBigTileLog>(a, staged, blocks, s);
+    }
 }
 
 template <uint32_t MODE>
@@ -275,7 +347,7 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
 // preparation into the first LDE pass, which only this kernel implements).
 bool ntt_fast_ok(const NttPassArgs& a, NttMode mode) {
     if (a.logR < 5 || a.logR > 8) return false;
-    if (a.tile_log != kSmallTileLog && a.tile_log != kBigTileLog) return false;
+    if (a.tile_log != kSmallTileLog && a.tile_log != kMidTileLog && a.tile_log != kBigTileLog) return false;
     const uint32_t logC = a.tile_log - a.logR;
     if (a.log_total < a.tile_log || a.logC != logC) return false;
     if (mode == NTT_DIT_LDE && !(a.logS < logC)) return false;

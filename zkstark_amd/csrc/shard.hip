@@ -111,8 +111,20 @@ struct zk_shard {
     // transport
     zk_shard_transport tp{};
     const RcclApi* rccl = nullptr;                     // non-null: tp is the built-in RCCL transport
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;                         // collectives on `stream`
+    ncclComm_t xcomm = nullptr;                        // chunked exchanges on `xstream`: their own communicator (null: comm serves both)
     bool force = false;                                // collectives even with G = 1
+    bool plain = false, single_build_stream = false, single_comm = false;   // zk_shard_options
+    // every collective waits for the previous collective of the OTHER stream (explicit HIP event, whatever the transport)
+    hipEvent_t ev_coll = nullptr;
+    hipStream_t last_coll_stream = nullptr;
+    // zk_shard_set_profiling: event pairs around the exchanges (kind 0: an exchange on xstream, 1: an exchange on a hashing
+    // stream = exposed in full, 2: a hashing stream stalled on a chunk's exchange)
+    bool profiling = false;
+    struct Timed { hipEvent_t a, b; int kind; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> ev_pool;
+    double tail_ms_acc = 0;
     // layout
     uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 21;
     static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
@@ -131,7 +143,8 @@ struct zk_shard {
     uint32_t* h_small = nullptr;                       // pinned scratch (subtree roots, flags)
     // root board
     RootBoard board;
-    bool use_board = false;
+    bool have_board = false;                           // the shared page is mapped: abort words work
+    bool use_board = false;                            // ... and the subtree roots travel through it
     uint64_t board_seq = 0;
     // settings (zk_shard_set_hash / _set_queries) and failure state
     int hash = ZK_HASH_SHA256;
@@ -165,7 +178,7 @@ int sync_peers(zk_shard* s, hipStream_t st, const char* what) {
         if (q == hipSuccess) return ZK_OK;
         if (q != hipErrorNotReady) return fail(ZK_ERR_HIP, "rank %d of %d: device error while waiting for %s: %s", s->rank, s->G, what, hipGetErrorString(q));
         if ((++spins & 127) == 0) {
-            if (s->use_board) {
+            if (s->have_board) {
                 const int ab = s->board.aborted_peer();
                 if (ab >= 0 && ab != s->rank)
                     return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d while this rank waited for %s", s->rank, s->G, ab,
@@ -185,7 +198,7 @@ int sync_peers(zk_shard* s, hipStream_t st, const char* what) {
 int rank_failed(zk_shard* s, int rc) {
     if (!rc || s->failed) return rc;
     s->failed = true;
-    if (s->use_board) s->board.post_abort((uint32_t)(-rc));
+    if (s->have_board) s->board.post_abort((uint32_t)(-rc));
     if (collectives(s)) fprintf(stderr, "[zk_shard] rank %d of %d failed (%d): %s\n", s->rank, s->G, rc, last_error());
     return rc;
 }
@@ -201,6 +214,7 @@ int rank_failed(zk_shard* s, int rc) {
 int rccl_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* recv, size_t words, void* stream) {
     zk_shard* s = static_cast<zk_shard*>(user);
     hipStream_t st = (hipStream_t)stream;
+    const ncclComm_t comm = (st == s->xstream && s->xcomm) ? s->xcomm : s->comm;     // one communicator per stream
     // the all-to-all of the four-step transpose: every pair exchanges one piece, all 7 xGMI links busy at once.
     // A failed Send / Recv must not leave the thread's group open (every later RCCL call would be undefined):
     // the group is always ended, then the first error is reported.
@@ -208,8 +222,8 @@ int rccl_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* re
     ncclResult_t first = ncclSuccess;
     int bad_peer = -1;
     for (int p = 0; p < s->G && first == ncclSuccess; ++p) {
-        ncclResult_t r = s->rccl->Send(send[p], words, ncclUint32, p, s->comm, st);
-        if (r == ncclSuccess) r = s->rccl->Recv(recv[p], words, ncclUint32, p, s->comm, st);
+        ncclResult_t r = s->rccl->Send(send[p], words, ncclUint32, p, comm, st);
+        if (r == ncclSuccess) r = s->rccl->Recv(recv[p], words, ncclUint32, p, comm, st);
         if (r != ncclSuccess) { first = r; bad_peer = p; }
     }
     const ncclResult_t end = s->rccl->GroupEnd();
@@ -220,24 +234,84 @@ int rccl_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* re
 }
 int rccl_all_gather(void* user, const uint32_t* send, uint32_t* recv, size_t words, void* stream) {
     zk_shard* s = static_cast<zk_shard*>(user);
-    NCCLCHK(s, s->rccl->AllGather(send, recv, words, ncclUint32, s->comm, (hipStream_t)stream));
+    const ncclComm_t comm = ((hipStream_t)stream == s->xstream && s->xcomm) ? s->xcomm : s->comm;
+    NCCLCHK(s, s->rccl->AllGather(send, recv, words, ncclUint32, comm, (hipStream_t)stream));
     return ZK_OK;
 }
 
 // ---- collectives with the byte accounting of zk_shard_stats -----------------------------------
+// A collective is enqueued on `st`: it first waits for the previous collective if that went to the other stream, so that
+// the order in which collectives EXECUTE is the program order on every rank whatever the transport does internally.
+int before_collective(zk_shard* s, hipStream_t st) {
+    if (s->last_coll_stream && s->last_coll_stream != st) HIPCHK(hipStreamWaitEvent(st, s->ev_coll, 0));
+    return ZK_OK;
+}
+int after_collective(zk_shard* s, hipStream_t st) {
+    HIPCHK(hipEventRecord(s->ev_coll, st));
+    s->last_coll_stream = st;
+    return ZK_OK;
+}
+// ---- zk_shard_set_profiling: event pairs, resolved at the end of a call --------------------------------------
+hipEvent_t timing_event(zk_shard* s) {
+    if (!s->ev_pool.empty()) { hipEvent_t e = s->ev_pool.back(); s->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ScopedTimed {                                   // brackets what is enqueued on `st` during its lifetime
+    zk_shard* s; hipStream_t st; int kind; hipEvent_t a = nullptr;
+    ScopedTimed(zk_shard* s_, hipStream_t st_, int kind_) : s(s_), st(st_), kind(kind_) {
+        if (s->profiling) { a = timing_event(s); if (a) (void)hipEventRecord(a, st); }
+    }
+    ~ScopedTimed() {
+        if (!a) return;
+        hipEvent_t b = timing_event(s);
+        if (b) { (void)hipEventRecord(b, st); s->timed.push_back({a, b, kind}); } else s->ev_pool.push_back(a);
+    }
+};
+void reset_timing(zk_shard* s) {
+    for (auto& t : s->timed) { s->ev_pool.push_back(t.a); s->ev_pool.push_back(t.b); }
+    s->timed.clear();
+    s->tail_ms_acc = 0;
+    s->stats.exchange_ms = s->stats.exposed_exchange_ms = s->stats.tail_ms = 0;
+    s->stats.exchanges = 0;
+}
+void collect_timing(zk_shard* s) {
+    if (!s->profiling) return;
+    for (auto& t : s->timed) {
+        float ms = 0;
+        if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            if (t.kind != 2) { s->stats.exchange_ms += ms; s->stats.exchanges += 1; }
+            if (t.kind != 0) s->stats.exposed_exchange_ms += ms;
+        }
+        s->ev_pool.push_back(t.a); s->ev_pool.push_back(t.b);
+    }
+    s->timed.clear();
+    s->stats.tail_ms = s->tail_ms_acc;
+}
 int all_to_all(zk_shard* s, const uint32_t* const* send, uint32_t* const* recv, size_t words, hipStream_t st) {
-    int rc = s->tp.all_to_all(s->tp.user, send, recv, words, (void*)st);
+    int rc = before_collective(s, st);
+    if (rc) return rc;
+    {
+        ScopedTimed tm(s, st, st == s->xstream ? 0 : 1);
+        rc = s->tp.all_to_all(s->tp.user, send, recv, words, (void*)st);
+    }
     if (rc) return rc > 0 ? fail(ZK_ERR_HIP, "transport all_to_all failed (%d)", rc) : rc;
     const double sent = 4.0 * (double)words * (s->G - 1);
     s->stats.sent_bytes += sent;
     s->stats.all_to_all_bytes += sent;
-    return ZK_OK;
+    return after_collective(s, st);
 }
 int all_gather(zk_shard* s, const uint32_t* send, uint32_t* recv, size_t words, hipStream_t st) {
-    int rc = s->tp.all_gather(s->tp.user, send, recv, words, (void*)st);
+    int rc = before_collective(s, st);
+    if (rc) return rc;
+    {
+        ScopedTimed tm(s, st, st == s->xstream ? 0 : 1);
+        rc = s->tp.all_gather(s->tp.user, send, recv, words, (void*)st);
+    }
     if (rc) return rc > 0 ? fail(ZK_ERR_HIP, "transport all_gather failed (%d)", rc) : rc;
     s->stats.sent_bytes += 4.0 * (double)words * (s->G - 1);
-    return ZK_OK;
+    return after_collective(s, st);
 }
 // min over the ranks of a host flag (setup only): one word through the transport
 int agree(zk_shard* s, bool ok, bool* all_ok) {
@@ -273,7 +347,7 @@ void host_merkle_top(const uint32_t* subroots, int G, std::vector<uint32_t>& hea
 // completes when a peer has left the proof.
 int poll_peer_abort(void* user) {
     zk_shard* s = static_cast<zk_shard*>(user);
-    if (!s->use_board) return 0;
+    if (!s->have_board) return 0;
     const int ab = s->board.aborted_peer();
     if (ab < 0 || ab == s->rank) return 0;
     return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d", s->rank, s->G, ab, -(int)s->board.bad_code);
@@ -282,7 +356,7 @@ int poll_peer_abort(void* user) {
 int commit_wait_failed(zk_shard* s, uint32_t lid, int rc) {
     if (!collectives(s)) return rc;
     const std::string inner = last_error();
-    const int ab = s->use_board ? s->board.aborted_peer() : -1;
+    const int ab = s->have_board ? s->board.aborted_peer() : -1;
     if (ab >= 0 && ab != s->rank)
         return fail(rc, "rank %d of %d: rank %d left the proof with error %d; the commitment of layer %u could not complete (%s)", s->rank, s->G, ab,
                     -(int)s->board.bad_code, lid, inner.c_str());
@@ -326,7 +400,10 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
             const bool two = s->bstream != nullptr;
             for (uint32_t c = 0; c < K; ++c) {
                 hipStream_t bs = (two && (c & 1u)) ? s->bstream : s->stream;
-                HIPCHK(hipStreamWaitEvent(bs, s->ev_chunk[c], 0));
+                {
+                    ScopedTimed stall(s, bs, 2);               // how long this hashing stream waits for chunk c's exchange
+                    HIPCHK(hipStreamWaitEvent(bs, s->ev_chunk[c], 0));
+                }
                 if ((rc = zk_dev_merkle_build_chunk(s->d_recv + (size_t)c * G * cc, lg, log_cnt - lk, nodes, m_log - lg, c, bs, s->hash))) return rc;
                 if (bs != s->stream) HIPCHK(hipEventRecord(s->ev_built[c], bs));
             }
@@ -464,6 +541,7 @@ int prove(zk_shard* s, Channel& ch) {
     s->info.public_last = s->last;
     s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
     s->stats.chunked_layers = 0;
+    reset_timing(s);
     ch.data.reserve(ch.data.size() + proof_data_len(s->log_n, s->log_b, s->queries));
     if ((rc = do_lde(s))) return rc;                                              // prover.rs:60-70
     if ((rc = commit_sharded(s, 0, L, root))) return rc;                           // prover.rs:81
@@ -489,6 +567,7 @@ int prove(zk_shard* s, Channel& ch) {
         // replication switch: fold locally, all-gather the G cyclic pieces, interleave to natural order, then the
         // commitment of that layer and every later round in one call on every rank (zk_tail_run)
         const size_t cnt = ((size_t)1 << (m_log - 1)) >> lg;
+        const double t_tail = now_us();
         uint32_t* piece = s->d_recv;
         if ((rc = zk_dev_fri_fold(s->dom_loc, layer_ptr(s, 1 + rho), piece, m_log - lg, rho, beta, s->stream))) return rc;
         const uint32_t* handed = piece;
@@ -504,6 +583,7 @@ int prove(zk_shard* s, Channel& ch) {
         rc = zk_tail_run(s->tail, handed, s->stream, &chan_view, s->hash, s->info.beta_raw + rho0, troots.data(), &free_term);
         ch = std::move(chan_view.ch);
         if (rc) return rc;
+        s->tail_ms_acc += (now_us() - t_tail) * 1e-3;
         for (uint32_t j = 0; j <= s->tail_rounds; ++j) memcpy(s->info.roots[1 + rho0 + j], troots.data() + 32 * j, 32);
     }
     (void)R;
@@ -514,6 +594,74 @@ int prove(zk_shard* s, Channel& ch) {
     s->info.query_raw = qraws[0];
     for (uint32_t k = 0; k < s->queries; ++k)                                      // prover.rs:266-289 per query
         if ((rc = decommit(s, ch, (size_t)qraws[k] % (s->N - 2 * s->B)))) return rc;
+    collect_timing(s);
+    return ZK_OK;
+}
+
+// ---- known-pattern exchange (zk_shard_create, zk_shard_self_test) -------------------------------------------
+// Every rank fills the piece it sends to peer p with pattern(rank, p, j), the exchanges run exactly as a commitment runs
+// them (plain on the main stream; in chunks on the exchange stream when the layout has chunked layers), and a kernel
+// checks that word j from peer q is pattern(q, rank, j).  Then an all-gather of 16 words per rank, checked on the host.
+int self_test(zk_shard* s) {
+    s->stats.selftest_ok = 0;
+    if (!collectives(s)) { s->stats.selftest_ok = 1; return ZK_OK; }
+    const double t0 = now_us();
+    const int G = s->G;
+    const uint32_t lg = s->lg, log_per = s->L - 2 * lg;           // the (rank, peer) piece of layer 0: the largest
+    const size_t per = (size_t)1 << log_per;
+    uint32_t* loc = layer_ptr(s, 0);
+    uint32_t* res = s->d_small + 2048 - 8;
+    const uint32_t* send[64];
+    uint32_t* recv[64];
+    int rc;
+    auto verdict = [&](const char* what, uint32_t log_chunks) -> int {
+        HIPCHK(hipMemsetAsync(res, 0xff, 8, s->stream));
+        HIPCHK(hipMemsetAsync(res, 0, 4, s->stream));
+        HIPCHK(launch_pattern_check(s->d_recv, (uint32_t)s->rank, log_per, lg, log_chunks, res, s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_small, res, 8, hipMemcpyDeviceToHost, s->stream));
+        int r2 = sync_peers(s, s->stream, what);
+        if (r2) return r2;
+        if (s->h_small[0]) {
+            const uint32_t i = s->h_small[1], cc = (uint32_t)(per >> log_chunks);
+            const uint32_t q = log_chunks ? (i / cc) % (uint32_t)G : i / (uint32_t)per;
+            return fail(ZK_ERR_HIP, "rank %d of %d: self-test of %s failed: %u of %zu received words are wrong, the first at receive index %u (the piece of rank %u)",
+                        s->rank, G, what, s->h_small[0], per * (size_t)G, i, q);
+        }
+        return ZK_OK;
+    };
+    // plain all-to-all on the main stream
+    HIPCHK(launch_pattern_fill(loc, (uint32_t)s->rank, log_per, lg, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_recv, 0, per * (size_t)G * 4, s->stream));
+    for (int g = 0; g < G; ++g) { send[g] = loc + (size_t)g * per; recv[g] = s->d_recv + (size_t)g * per; }
+    if ((rc = all_to_all(s, send, recv, per, s->stream))) return rc;
+    if ((rc = verdict("the all-to-all on the main stream", 0))) return rc;
+    // the chunked form on the exchange stream, if this prover will use it
+    if (s->chunked_mask) {
+        const uint32_t lk = zk_shard::kLogChunks, K = 1u << lk;
+        const size_t cc = per >> lk;
+        HIPCHK(hipMemsetAsync(s->d_recv, 0, per * (size_t)G * 4, s->stream));
+        HIPCHK(hipEventRecord(s->ev_layer, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->xstream, s->ev_layer, 0));
+        for (uint32_t c = 0; c < K; ++c) {
+            for (int g = 0; g < G; ++g) { send[g] = loc + (size_t)g * per + (size_t)c * cc; recv[g] = s->d_recv + ((size_t)c * G + g) * cc; }
+            if ((rc = all_to_all(s, send, recv, cc, s->xstream))) return rc;
+        }
+        HIPCHK(hipEventRecord(s->ev_chunk[0], s->xstream));
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_chunk[0], 0));
+        if ((rc = verdict("the chunked all-to-all on the exchange stream", lk))) return rc;
+    }
+    // all-gather: 16 words per rank
+    for (uint32_t j = 0; j < 16; ++j) s->h_small[j] = shard_pattern((uint32_t)s->rank, 0xA6u, j);
+    HIPCHK(hipMemcpyAsync(s->d_small, s->h_small, 64, hipMemcpyHostToDevice, s->stream));
+    if ((rc = all_gather(s, s->d_small, s->d_small + 64, 16, s->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(s->h_small + 64, s->d_small + 64, 64 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
+    if ((rc = sync_peers(s, s->stream, "the self-test all-gather"))) return rc;
+    for (int q = 0; q < G; ++q)
+        for (uint32_t j = 0; j < 16; ++j)
+            if (s->h_small[64 + 16 * q + j] != shard_pattern((uint32_t)q, 0xA6u, j))
+                return fail(ZK_ERR_HIP, "rank %d of %d: self-test of the all-gather failed: word %u of rank %d's part is wrong", s->rank, G, j, q);
+    s->stats.selftest_ok = 1;
+    s->stats.selftest_ms = (now_us() - t0) * 1e-3;
     return ZK_OK;
 }
 
@@ -560,8 +708,8 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
         if (opt->min_chunk_log) min_chunk_log = opt->min_chunk_log;
         if (opt->overlap_min_log) overlap_min_log = opt->overlap_min_log;
         force = opt->force_collectives != 0;
+        if (opt->plain_collectives) overlap_min_log = 99;          // plain collectives only: nothing is exchanged in chunks
     }
-    if (getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1) overlap_min_log = 99;   // operational switch: plain collectives only
     const uint32_t L = log_n + log_b, R = log_n;
     if (L < 2 * lg + min_chunk_log)
         return fail(ZK_ERR_INVALID, "zk_shard_plan: domain 2^%u is too small to shard over %d ranks: use zk_prove", L, world);
@@ -596,11 +744,29 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
 int zk_shard_destroy(zk_shard* s) {
     if (!s) return ZK_OK;
     (void)hipSetDevice(s->device);
-    // after an error a collective may still sit on the streams waiting for a peer: abort the communicator first
-    if (s->comm && s->rccl && s->failed) { (void)s->rccl->CommAbort(s->comm); s->comm = nullptr; }
+    // after an error a collective may still sit on the streams waiting for a peer: abort the communicators first
+    if (s->rccl && s->failed) {
+        if (s->xcomm) { (void)s->rccl->CommAbort(s->xcomm); s->xcomm = nullptr; }
+        if (s->comm) { (void)s->rccl->CommAbort(s->comm); s->comm = nullptr; }
+    }
+    if (s->failed && !s->rccl && collectives(s)) {
+        // a caller's transport cannot be aborted from here: if one of its collectives is still pending, waiting for the
+        // streams (or freeing device memory, which synchronises the device) would hang for ever
+        bool pending = false;
+        for (hipStream_t st : {s->stream, s->xstream, s->bstream})
+            if (st && hipStreamQuery(st) == hipErrorNotReady) pending = true;
+        if (pending) {
+            fprintf(stderr, "[zk_shard] rank %d of %d: a collective of the caller's transport is still pending after a failure; "
+                            "the prover's streams and device buffers are leaked instead of waited for\n", s->rank, s->G);
+            s->board.close();
+            delete s;
+            return ZK_OK;
+        }
+    }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->xstream) (void)hipStreamSynchronize(s->xstream);
     if (s->bstream) (void)hipStreamSynchronize(s->bstream);
+    if (s->xcomm && s->rccl) (void)s->rccl->CommDestroy(s->xcomm);
     if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
     s->board.close();
     if (s->tail) zk_ctx_destroy(s->tail);
@@ -612,6 +778,9 @@ int zk_shard_destroy(zk_shard* s) {
     for (void* p : {(void*)s->h_goff, (void*)s->h_gall, (void*)s->h_small})
         if (p) (void)hipHostFree(p);
     if (s->ev_layer) (void)hipEventDestroy(s->ev_layer);
+    if (s->ev_coll) (void)hipEventDestroy(s->ev_coll);
+    for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->ev_chunk) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->ev_built) if (e) (void)hipEventDestroy(e);
     if (s->xstream) (void)hipStreamDestroy(s->xstream);
@@ -645,8 +814,13 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         if (opt->min_chunk_log) s->min_chunk_log = opt->min_chunk_log;
         if (opt->overlap_min_log) s->overlap_min_log = opt->overlap_min_log;
         s->force = opt->force_collectives != 0;
+        s->plain = opt->plain_collectives != 0;
+        s->single_build_stream = opt->single_build_stream != 0;
+        s->single_comm = opt->single_communicator != 0;
     }
-    if (const char* e = getenv("ZK_SHARD_TIMEOUT_S")) { const double v = atof(e); if (v > 0) s->timeout_s = v; }
+    // bound of every host-side wait on a peer: the option, else the environment (documented in INTEGRATION.md), else 120 s
+    if (opt && opt->timeout_s > 0) s->timeout_s = opt->timeout_s;
+    else if (const char* e = getenv("ZK_SHARD_TIMEOUT_S")) { const double v = atof(e); if (v > 0) s->timeout_s = v; }
     int rc = ZK_OK;
     auto bail = [&](int code) { zk_shard_destroy(s); return code; };
 #define HIPCHK_S(expr)                                                                        \
@@ -673,9 +847,13 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         HIPCHK_S(hipStreamCreateWithPriority(&s->xstream, hipStreamNonBlocking, greatest));
     }
     HIPCHK_S(hipEventCreateWithFlags(&s->ev_layer, hipEventDisableTiming));
+    HIPCHK_S(hipEventCreateWithFlags(&s->ev_coll, hipEventDisableTiming));
     for (hipEvent_t& e : s->ev_chunk) HIPCHK_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : s->ev_built) HIPCHK_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (!(getenv("ZK_SHARD_ONE_BUILD_STREAM") && atoi(getenv("ZK_SHARD_ONE_BUILD_STREAM")))) HIPCHK_S(hipStreamCreateWithFlags(&s->bstream, hipStreamNonBlocking));
+    if (!s->single_build_stream) HIPCHK_S(hipStreamCreateWithFlags(&s->bstream, hipStreamNonBlocking));
+    // small device / pinned scratch (subtree roots, flags, the second communicator's id, self-test results): needed by the set-up below
+    if ((rc = dalloc(s, &s->d_small, 8192))) return bail(rc);
+    HIPCHK_S(hipHostMalloc((void**)&s->h_small, 8192));
     // transport
     if (transport) {
         s->tp = *transport;
@@ -699,6 +877,31 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         s->tp.all_to_all = rccl_all_to_all;
         s->tp.all_gather = rccl_all_gather;
         s->stats.native_rccl = 1;
+        s->stats.communicators = 1;
+        // The chunked exchanges run on xstream beside the hashing: they get a communicator of their own, so that no
+        // communicator is ever driven from two streams.  Rank 0 draws the second id, the first communicator carries it.
+        if (plan.chunked_mask && !s->single_comm) {
+            ncclUniqueId id2;
+            memset(&id2, 0, sizeof id2);
+            if (rank == 0) {
+                r = s->rccl->GetUniqueId(&id2);
+                if (r != ncclSuccess) { s->failed = true; return bail(fail(ZK_ERR_HIP, "ncclGetUniqueId (exchange communicator) failed: %s", s->rccl->GetErrorString(r))); }
+            }
+            memcpy(s->h_small, &id2, sizeof id2);
+            HIPCHK_S(hipMemcpyAsync(s->d_small, s->h_small, sizeof id2, hipMemcpyHostToDevice, s->stream));
+            if ((rc = all_gather(s, s->d_small, s->d_small + 32, 32, s->stream))) { s->failed = true; return bail(rc); }
+            HIPCHK_S(hipMemcpyAsync(s->h_small + 32, s->d_small + 32, sizeof id2, hipMemcpyDeviceToHost, s->stream));   // rank 0's part
+            if ((rc = sync_peers(s, s->stream, "the distribution of the exchange communicator's id"))) { s->failed = true; return bail(rc); }
+            memcpy(&id2, s->h_small + 32, sizeof id2);
+            r = s->rccl->CommInitRank(&s->xcomm, world, id2, rank);
+            if (r != ncclSuccess) { s->xcomm = nullptr; s->failed = true; return bail(fail(ZK_ERR_HIP, "ncclCommInitRank(exchange communicator, rank %d of %d) failed: %s", rank, world, s->rccl->GetErrorString(r))); }
+            r1 = s->rccl->CommCount(s->xcomm, &nr); r2 = s->rccl->CommUserRank(s->xcomm, &ur);
+            if (r1 != ncclSuccess || r2 != ncclSuccess || nr != world || ur != rank) {
+                s->failed = true;
+                return bail(fail(ZK_ERR_HIP, "zk_shard_create: exchange communicator mismatch: ncclCommCount = %d (expected %d), ncclCommUserRank = %d (expected %d)", nr, world, ur, rank));
+            }
+            s->stats.communicators = 2;
+        }
     }
     // this rank's coset: shift w h^rank, blow-up B/G; the replicated tail: layer ns of the proof is layer 0 of the
     // domain with n' = n >> ns and shift w^(2^ns)
@@ -723,16 +926,16 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     s->gather_words = (size_t)(4 + 2 * ns) * (1 + 8 * (size_t)L) + 64;
     if ((rc = dalloc(s, &s->d_trace, s->n * 4)) || (rc = dalloc(s, &s->d_coef, 2 * s->n * 4)) || (rc = dalloc(s, &s->d_layers, layer_words * 4)) ||
         (rc = dalloc(s, &s->d_trees, tree_words * 4)) || (rc = dalloc(s, &s->d_recv, NL * 4)) || (rc = dalloc(s, &s->d_gbuf, repl * 4)) ||
-        (rc = dalloc(s, &s->d_repl, repl * 4)) || (rc = dalloc(s, &s->d_small, 4096)) || (rc = dalloc(s, &s->d_goff, s->gather_slots * 8)) ||
+        (rc = dalloc(s, &s->d_repl, repl * 4)) || (rc = dalloc(s, &s->d_goff, s->gather_slots * 8)) ||
         (rc = dalloc(s, &s->d_gout, s->gather_words * 4)) || (rc = dalloc(s, &s->d_gall, s->gather_words * 4 * (size_t)world)))
         return bail(rc);
     HIPCHK_S(hipHostMalloc((void**)&s->h_goff, s->gather_slots * 8));
     HIPCHK_S(hipHostMalloc((void**)&s->h_gall, s->gather_words * 4 * (size_t)world));
-    HIPCHK_S(hipHostMalloc((void**)&s->h_small, 4096));
     s->tops.resize(ns + 1);
     s->device_bytes += (double)zk_ctx_device_bytes(s->tail);
-    // subtree roots through shared memory when every rank can map the object (one node); else the all-gather
-    if (collectives(s) && id && !(opt && opt->no_root_board) && !(getenv("ZK_SHARD_PLAIN") && atoi(getenv("ZK_SHARD_PLAIN")) == 1)) {
+    // A shared-memory page when every rank can map the object (one node): the abort words always, and the subtree roots
+    // unless the options ask for the all-gather (no_root_board, plain_collectives)
+    if (collectives(s) && id) {
         uint8_t dg[32];
         Sha256 hsh; hsh.update(id, ZK_SHARD_ID_BYTES); hsh.finalize(dg);
         char name[64];
@@ -744,12 +947,16 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         bool mapped = false;
         if ((rc = agree(s, all && ok, &mapped))) return bail(rc);   // everybody has mapped it: the name can go
         if (rank == 0) shm_unlink(name);
-        s->use_board = mapped;
+        s->have_board = mapped;
+        s->use_board = mapped && !(opt && opt->no_root_board) && !s->plain;
         if (!mapped) s->board.close();
     }
     HIPCHK_S(hipStreamSynchronize(s->stream));
 #undef HIPCHK_S
-    if (s->use_board) committer_set_poll(s->committer, poll_peer_abort, s);
+    committer_set_poll(s->committer, s->have_board ? poll_peer_abort : nullptr, s, s->timeout_s);
+    // known-pattern exchange through the transport, at the size of the largest piece: nothing reaches a proof through a
+    // transport that permutes or drops data, and RCCL's lazily built connections are up before the first proof
+    if ((rc = self_test(s))) { s->failed = true; if (s->have_board) s->board.post_abort((uint32_t)(-rc)); return bail(rc); }
     s->stats.sharded_layers = ns;
     s->stats.root_board = s->use_board ? 1 : 0;
     s->stats.device_bytes = s->device_bytes;
@@ -801,8 +1008,10 @@ int zk_shard_lde_commit(zk_shard* s, uint8_t root_out[32]) {
     s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
     s->stats.chunked_layers = 0;
     if (s->failed) return fail(ZK_ERR_STATE, "zk_shard_lde_commit: this rank left an earlier call with an error; destroy the prover");
+    reset_timing(s);
     int rc = do_lde(s);                                         // prover.rs:60-70, each rank its cosets
     if (!rc) rc = commit_sharded(s, 0, s->L, root_out);         // the all-to-all transpose + prover.rs:81
+    if (!rc) collect_timing(s);
     return rank_failed(s, rc);
 }
 
@@ -823,6 +1032,18 @@ int zk_shard_set_queries(zk_shard* s, uint32_t n_queries) {
 int zk_shard_inject_failure(zk_shard* s, int code) {
     if (!s) return fail(ZK_ERR_INVALID, "null prover");
     return rank_failed(s, fail(code < 0 ? code : ZK_ERR_STATE, "injected failure on rank %d", s->rank));
+}
+
+int zk_shard_self_test(zk_shard* s) {
+    if (!s) return fail(ZK_ERR_INVALID, "null prover");
+    HIPCHK(hipSetDevice(s->device));
+    if (s->failed) return fail(ZK_ERR_STATE, "zk_shard_self_test: this rank left an earlier call with an error; destroy the prover");
+    return rank_failed(s, self_test(s));
+}
+int zk_shard_set_profiling(zk_shard* s, int on) {
+    if (!s) return fail(ZK_ERR_INVALID, "null prover");
+    s->profiling = on != 0;
+    return ZK_OK;
 }
 
 int zk_shard_last_transcript(const zk_shard* s, zk_transcript_info* out) {

@@ -14,7 +14,8 @@ struct RcclApi;
 const RcclApi* rccl_api();                 // nullptr + fail() recorded when the library cannot be loaded
 
 // zkstark.hip: consulted by a committer while it waits for posted digests (non-zero return ends the wait)
-void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user);
+// timeout_s > 0: also the bound of that wait
+void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user, double timeout_s = 0.0);
 
 }  // namespace impl
 }  // namespace zk

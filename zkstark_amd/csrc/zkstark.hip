@@ -130,15 +130,13 @@ int do_lde(zk_ctx* c) {
     return rc;
 }
 
-// Sub-tree of the handed-over digests one host thread reduces alone (ZK_HOST_SUB_LOG, tuning only; default 2^8 digests)
-uint32_t host_sub_log() {
-    static const uint32_t v = [] {
-        const char* e = getenv("ZK_HOST_SUB_LOG");
-        const uint32_t x = e ? (uint32_t)atoi(e) : kHostTopSingle;
-        return (x < 4 || x > kMaxHostLog) ? kHostTopSingle : x;
-    }();
-    return v;
-}
+// Sub-tree of the handed-over digests one host thread reduces alone: 2^8 digests (255 nodes, ~5 us).  Build-time constant
+// (ZK_BUILD_DEFS="-DZK_HOST_SUB_LOG=7"; profiles/r03_ab_host_team.txt swept it).
+#ifndef ZK_HOST_SUB_LOG
+#define ZK_HOST_SUB_LOG 8
+#endif
+static_assert(ZK_HOST_SUB_LOG >= 4 && ZK_HOST_SUB_LOG <= (int)kMaxHostLog, "host sub-tree size");
+constexpr uint32_t host_sub_log() { return ZK_HOST_SUB_LOG; }
 // How much of tree `tree` the host finishes: the top `host_top` levels of SHA-256 trees larger than that.
 uint32_t top_of(const zk_ctx* c, uint32_t tree) {
     if (c->hash != 0 || !c->host_top) return 0;
@@ -502,6 +500,12 @@ extern "C" {
 
 const char* zk_last_error(void) { return last_error(); }
 int zk_host_hash_mode(void) { return host_sha_wide_available() ? 2 : host_sha_available() ? 1 : 0; }
+int zk_host_set_hash_mode(int mode) {
+    if (mode < 0 || mode > 2) return fail(ZK_ERR_INVALID, "zk_host_set_hash_mode: mode %d out of range (0 portable, 1 SHA extensions, 2 + AVX-512)", mode);
+    host_sha_use_extensions(mode >= 1);
+    host_sha_use_wide(mode >= 2);
+    return ZK_OK;
+}
 
 uint32_t zk_field_add(uint32_t a, uint32_t b) { return add(a % P, b % P); }
 uint32_t zk_field_sub(uint32_t a, uint32_t b) { return sub(a % P, b % P); }
@@ -532,9 +536,8 @@ static int ctx_team(zk_ctx* c) {
     c->pool = nullptr;
     if (!want) return ZK_OK;
     // the commitments of one big proof are up to 1.6 ms apart (a 2^24-leaf launch): the team spins across them
-    // (ZK_HOST_TEAM_SPIN_US, default 5 ms), or every tree top would pay a futex wake-up
-    double spin_us = 5000.0;
-    if (const char* e = getenv("ZK_HOST_TEAM_SPIN_US")) { const double v = atof(e); if (v > 0) spin_us = v; }
+    // (5 ms), or every tree top would pay a futex wake-up
+    const double spin_us = 5000.0;
     c->pool = new (std::nothrow) Pool(want, spin_us);
     return c->pool ? (int)ZK_OK : fail(ZK_ERR_NOMEM, "out of host memory");
 }
@@ -610,9 +613,6 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     if (host_sha_available()) {            // without the SHA extensions the device builds every tree to the root
         c->host_top = 8;
         c->host_tail = 9;
-        if (const char* e = getenv("ZK_HOST_TOP_LOG")) c->host_top = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 8;
-        if (const char* e = getenv("ZK_HOST_TAIL_LOG")) c->host_tail = (uint32_t)atoi(e) <= kMaxHostLog ? (uint32_t)atoi(e) : 9;
-        if (!c->host_top) c->host_tail = 0;
     }
     if (int prc = ctx_team(c)) { zk_ctx_destroy(c); return prc; }
 #undef HIPCHK_C
@@ -740,7 +740,7 @@ int zk_lde(zk_ctx* c) {
     static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
     const double t0 = now_us();
     int rc = do_lde(c);
-    if (timing) fprintf(stderr, "[zk timing] lde: enqueue of %u passes %.1f us\n", 2 * c->dom->plan.nd + (c->log_n > kFusePrepMaxLogN ? 1 : 0), now_us() - t0);
+    if (timing) fprintf(stderr, "[zk timing] lde: enqueue of %u passes %.1f us\n", 2 * c->dom->plan.nd, now_us() - t0);
     return rc;
 }
 
@@ -1149,10 +1149,13 @@ struct zk_committer {
     // optional: consulted while waiting for the posted digests (shard.hip: has a peer left the proof?)
     int (*poll)(void*) = nullptr;
     void* poll_user = nullptr;
+    double timeout_s = 30.0;        // bound of that wait (shard.hip passes the prover's own: the launch may sit behind an exchange)
 };
 extern "C++" {
 namespace zk { namespace impl {
-void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user) { if (k) { k->poll = poll; k->poll_user = user; } }
+void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user, double timeout_s) {
+    if (k) { k->poll = poll; k->poll_user = user; if (timeout_s > 0) k->timeout_s = timeout_s; }
+}
 } }
 }
 int zk_committer_destroy(zk_committer* k) {
@@ -1184,14 +1187,20 @@ int zk_committer_create(int device, zk_committer** out) {
     if (e != hipSuccess) { zk_committer_destroy(k); return fail(ZK_ERR_HIP, "zk_committer_create: %s", hipGetErrorString(e)); }
     memset(k->h_mail, 0, kMailValsOff * 4);
     k->top = host_sha_available() ? 8 : 0;
-    if (const char* v = getenv("ZK_HOST_TOP_LOG")) k->top = (uint32_t)atoi(v) <= kMaxHostLog ? (uint32_t)atoi(v) : k->top;
     *out = k;
+    return ZK_OK;
+}
+// Hand-over depth of later commits, as zk_ctx_set_host_levels' top_log (0: the device builds every tree to the root).
+int zk_committer_set_top(zk_committer* k, uint32_t top_log) {
+    if (!k) return fail(ZK_ERR_INVALID, "null committer");
+    if (top_log > kHostTopSingle) return fail(ZK_ERR_INVALID, "zk_committer_set_top: need top_log <= %u (one thread reduces the top)", kHostTopSingle);
+    k->top = top_log;
     return ZK_OK;
 }
 // Waits for the digests a commit launch posted; with a hand-over depth, hashes the levels above on this thread
 // and queues the copy of those nodes into d_nodes.
 static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nodes, hipStream_t s, uint8_t root_out[32]) {
-    int rc = wait_flag(k->h_mail, m.seq, s, k->poll, k->poll_user);
+    int rc = wait_flag(k->h_mail, m.seq, s, k->poll, k->poll_user, k->timeout_s);
     if (rc) return rc;
     if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
     const size_t cnt = (size_t)1 << m.top;
@@ -1259,6 +1268,10 @@ int zk_dev_merkle_finish(uint32_t* d_nodes, uint32_t log_m, uint32_t log_chunks,
     if (!d_nodes || log_m > 30 || log_chunks > 10 || log_chunks > log_m || (hash_kind != 0 && hash_kind != 1))
         return fail(ZK_ERR_INVALID, "zk_dev_merkle_finish: bad argument");
     HIPCHK(launch_merkle_finish(d_nodes, log_m, log_chunks, (hipStream_t)stream, dev_prof(), hash_kind));
+    return ZK_OK;
+}
+int zk_dev_set_merkle_latency_log(uint32_t log_nodes) {
+    if (!set_merkle_latency_log(log_nodes)) return fail(ZK_ERR_INVALID, "zk_dev_set_merkle_latency_log: need 12 <= log_nodes <= 24 (0 = default)");
     return ZK_OK;
 }
 int zk_dev_merkle_build(const uint32_t* d_vals, uint32_t log_m, uint32_t* d_nodes, void* stream) {
