@@ -57,7 +57,7 @@ def test_merkle_rejects_non_power_of_two(zk):
 
 
 # ---- NTT ------------------------------------------------------------------------
-@pytest.mark.parametrize("log_m", [1, 2, 3, 7, 8, 9, 10, 13, 14, 16, 17, 20])
+@pytest.mark.parametrize("log_m", [1, 2, 3, 7, 8, 9, 10, 13, 14, 16, 17, 20, 21, 22])      # 21, 22: the 4096-word tile (round 4)
 def test_ntt_forward_inverse_match_oracle(zk, orc, log_m):
     rng = np.random.default_rng(200 + log_m)
     x = rand_field(rng, 1 << log_m)
@@ -79,7 +79,10 @@ def test_lde_reference_checkpoints(zk):
     assert list(f[-3:]) == [800520420, 1199720174, 1076821037]
 
 
-@pytest.mark.parametrize("log_n,log_b", [(2, 1), (4, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1), (9, 5), (16, 5), (20, 2)])
+# (18, 3), (19, 3): LDE passes on the 4096-word tile; (21, 1): the inverse passes on it and coefficient blocks of half a tile in LDS;
+# (16, 5): a first LDE pass the register-radix kernel does not take (separate coefficient sweep)
+@pytest.mark.parametrize("log_n,log_b", [(2, 1), (4, 3), (5, 2), (8, 3), (9, 4), (10, 3), (13, 3), (14, 3), (17, 3), (16, 1), (9, 5), (16, 5), (20, 2),
+                                         (18, 3), (19, 3), (21, 1), (12, 2), (15, 4)])
 def test_lde_matches_oracle(zk, orc, log_n, log_b):
     rng = np.random.default_rng(300 + log_n * 8 + log_b)
     trace = rand_field(rng, (1 << log_n) - 1)   # arbitrary trace values, not only Fibonacci-square

@@ -73,7 +73,7 @@ def test_sharded_multirank_one_gpu(orc, world, log_n, log_b, lat):
         assert data == want.proof and state == want.state, f"rank {rank}"
 
 
-@pytest.mark.parametrize("log_n,log_b,rank_exp", [(6, 0, 5), (7, 1, 3), (9, 2, 1), (10, 3, 0), (13, 0, 7)])
+@pytest.mark.parametrize("log_n,log_b,rank_exp", [(6, 0, 5), (7, 1, 3), (9, 2, 1), (10, 3, 0), (13, 0, 7), (16, 0, 3)])
 def test_shard_domain_primitives_match_definition(zk, orc, log_n, log_b, rank_exp):
     """zk_dev_lde / zk_dev_compose / zk_dev_fri_fold on a shard domain (shift = w * h_global^r, blow-up
     B/G down to 1) against the formulas written out directly in the CPU test double."""

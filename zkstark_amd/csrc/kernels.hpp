@@ -77,23 +77,20 @@ enum NttMode : uint32_t {
     NTT_DIT_LDE = 2,    // first forward pass of the LDE: reads n prepared coefficients, writes N = n*B values
 };
 
-// Workgroup tile of an NTT pass, in words: 8192 for big transforms (long row segments: HBM traffic 1.00-1.03 x the
-// algorithmic bytes), 4096 for passes over 2^21 .. 2^22 words (one workgroup per compute unit is a chain of latencies:
-// table look-up, loads, two register DFTs, stores; two lighter workgroups per unit overlap theirs, and a radix-128 row
-// segment is still a whole 128-byte line), 2048 for passes over <= 2^20 words (latency-bound: 4 x the workgroups, a
-// quarter of the elements per thread).  At 2^21 the 2048-word tile fetched 2 x the bytes (64-byte row segments at radix
-// 128, PMC FETCH_SIZE), so that size takes the middle tile.  Build-time constants (ZK_BUILD_DEFS to A/B them).
+// Workgroup tile of an NTT pass, in words: 4096 for passes over more than 2^20 words, 2048 below.  A pass is a chain of
+// latencies per workgroup (table look-up, loads, two register DFTs, stores) and, in this field, VALU-heavy (P > 2^31: every
+// add / sub carries its correction), so it wants many light workgroups per compute unit: eight 4096-word workgroups
+// (16.5 KiB of LDS, <= 64 VGPRs) hold 8 waves per SIMD, where the 8192-word tile of rounds 1-3 held 4.  Measured on the
+// 2^24-word passes of a 2^24 proof (rocprofv3, profiles/r04_ab_ntt_tile.txt): 31.1 us against 32.7 us in place, 37.3 against
+// 40.1 us for the first LDE pass; a radix-128 row segment is still a whole 128-byte line (HBM traffic 1.00 x algorithmic).
+// The 2048-word tile has 64-byte segments at radix 128 (2 x the fetched bytes at 2^21, round 3), fine for the latency-bound
+// passes over <= 2^20 words whose data sits in L2.  Build-time constant (ZK_BUILD_DEFS="-DZK_NTT_SMALL_MAX_LOG=..." to A/B it).
 #ifndef ZK_NTT_SMALL_MAX_LOG
 #define ZK_NTT_SMALL_MAX_LOG 20
 #endif
-#ifndef ZK_NTT_MID_MAX_LOG
-#define ZK_NTT_MID_MAX_LOG 22
-#endif
-constexpr uint32_t kBigTileLog = 13, kMidTileLog = 12, kSmallTileLog = 11;
-constexpr uint32_t kNttSmallTileMaxLog = ZK_NTT_SMALL_MAX_LOG, kNttMidTileMaxLog = ZK_NTT_MID_MAX_LOG;
-inline uint32_t ntt_tile_log(uint32_t log_total) {
-    return log_total <= kNttSmallTileMaxLog ? kSmallTileLog : log_total <= kNttMidTileMaxLog ? kMidTileLog : kBigTileLog;
-}
+constexpr uint32_t kMidTileLog = 12, kSmallTileLog = 11;
+constexpr uint32_t kNttSmallTileMaxLog = ZK_NTT_SMALL_MAX_LOG;
+inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total <= kNttSmallTileMaxLog ? kSmallTileLog : kMidTileLog; }
 
 struct NttPassArgs {
     const uint32_t* src;

@@ -1,13 +1,12 @@
 // ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256).
 //
 // Same pass semantics as ntt_pass_kernel (kernels.hip): the array is [A][R][S], a workgroup owns
-// C columns x R rows.  The tile is R*C = 8192 words for large transforms, 4096 for mid-size ones and
-// 2048 for small ones (NttPassArgs.tile_log; kernels.hpp: ntt_tile_log): passes over few words are
-// latency-bound, not bandwidth-bound, and want more, lighter workgroups per compute unit.
+// C columns x R rows.  The tile is R*C = 4096 words, 2048 for transforms of up to 2^20 words
+// (NttPassArgs.tile_log; kernels.hpp: ntt_tile_log says why: many light workgroups per compute unit).
 // The R-point transform is a four-step inside the tile, R = Ra*Rb with Ra, Rb <= 16:
 //
 //   step 1  thread (tb, c): loads rows ta*Rb + tb, ta < Ra, straight into registers (lanes run
-//           along c: one 256 B row segment per wave-instruction), applies the inter-pass twiddle
+//           along c: whole 128 B row segments), applies the inter-pass twiddle
 //           as a running product, runs the Ra-point DFT in registers with compile-time
 //           twiddles (17 multiplies for 16 points, 5 for 8), multiplies by w_R^(tb*ka) and
 //           writes row ka*Rb + tb of the LDS tile;
@@ -323,11 +322,8 @@ hipError_t launch3(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
 
 template <uint32_t MODE, int LA, int LB>
 hipError_t launch2(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream_t s) {
-    switch (a.tile_log) {
-        case kSmallTileLog: return launch3<MODE, LA, LB, (int)kSmallTileLog>(a, staged, blocks, s);
-        case kMidTileLog: return launch3<MODE, LA, LB, (int)kMidTileLog>(a, staged, blocks, s);
-        default: return launch3<MODE, LA, LB, (int)kBigTileLog>(a, staged, blocks, s);
-    }
+    return a.tile_log == kSmallTileLog ? launch3<MODE, LA, LB, (int)kSmallTileLog>(a, staged, blocks, s)
+                                       : launch3<MODE, LA, LB, (int)kMidTileLog>(a, staged, blocks, s);
 }
 
 template <uint32_t MODE>
@@ -347,7 +343,7 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
 // preparation into the first LDE pass, which only this kernel implements).
 bool ntt_fast_ok(const NttPassArgs& a, NttMode mode) {
     if (a.logR < 5 || a.logR > 8) return false;
-    if (a.tile_log != kSmallTileLog && a.tile_log != kMidTileLog && a.tile_log != kBigTileLog) return false;
+    if (a.tile_log != kSmallTileLog && a.tile_log != kMidTileLog) return false;
     const uint32_t logC = a.tile_log - a.logR;
     if (a.log_total < a.tile_log || a.logC != logC) return false;
     if (mode == NTT_DIT_LDE && !(a.logS < logC)) return false;
