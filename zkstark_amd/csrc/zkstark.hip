@@ -514,7 +514,25 @@ uint32_t zk_field_neg(uint32_t a) { return neg(a % P); }
 uint32_t zk_field_inv(uint32_t a) { return invmod(a % P); }
 uint32_t zk_field_pow(uint32_t a, uint32_t e) { return powmod(a, e); }
 uint32_t zk_field_from_u32(uint32_t v) { return v % P; }
-uint32_t zk_field_generator(void) { return GEN_W; }
+// field.rs:52-86 Gf::generator(): the first x >= 2 with x^((P-1)/q) != 1 for every prime factor q of P - 1.  Searched as the
+// reference searches it (unique prime factors by trial division, then candidates in order), once; the kernels use the
+// constant GEN_W, which this search must -- and does -- return (5; tests/test_cabi.py pins it against the oracle's search).
+uint32_t zk_field_generator(void) {
+    static const uint32_t g = [] {
+        uint32_t factors[32], nf = 0, p = P - 1;
+        for (uint32_t it = 2; p != 1; ++it) {              // field.rs:56-67
+            if (p % it == 0) factors[nf++] = it;
+            while (p % it == 0) p /= it;
+        }
+        for (uint32_t x = 2; x < P; ++x) {                 // field.rs:78-86
+            bool primitive = true;
+            for (uint32_t i = 0; i < nf && primitive; ++i) primitive = powmod(x, (P - 1) / factors[i]) != 1;   // field.rs:70-76: (P-1) * factor^-1 = (P-1) / factor
+            if (primitive) return x;
+        }
+        return 0u;
+    }();
+    return g;
+}
 // field.rs:45-49 order(): the reference brute-forces it; P - 1 = 3 * 2^30 gives it in 32 squarings
 uint32_t zk_field_order(uint32_t a) {
     a %= P;
