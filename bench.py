@@ -113,6 +113,8 @@ def spawn_ranks(args):
 # rung of the transport ladder.  Budget: every rung has its own deadline, the whole ladder prints a line inside ~300 s.
 LADDER = (("native", False), ("native", True), ("torch", True))      # (transport, plain collectives)
 RUNG_BUDGET_S = (50.0, 40.0, 40.0)     # rendezvous + communicator(s) + self-test + first verified proof, per rung
+if os.environ.get("ZK_BENCH_RUNG_BUDGET_S"):                 # rehearsals shorten the deadlines (tests/test_bench_cli.py)
+    RUNG_BUDGET_S = tuple(float(x) for x in os.environ["ZK_BENCH_RUNG_BUDGET_S"].split(","))
 RUN_BUDGET_S = 150.0                   # everything after the first proof (timed steps, secondary legs, parity proof)
 SHARD_TIMEOUT_S = 20.0                 # zk_shard_options.timeout_s: every host-side wait on a peer inside the library
 

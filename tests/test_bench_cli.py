@@ -45,6 +45,10 @@ def test_bench_n2_rehearsal_on_one_gpu():
 @pytest.mark.parametrize("env_extra,want_transport", [
     ({"ZK_BENCH_TRANSPORT": "torch"}, "torch"),                      # torch.distributed's RCCL communicator on device pointers
     ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "1"}, "torch"),            # the native transport "fails": the line says so and falls back
+    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "id"}, "torch"),           # rank 0 cannot even draw the unique id: every rank learns it together
+    # the native transport HANGS (as ncclCommInitRank can): the worker's watchdog ends it, the supervisor starts a fresh
+    # worker on the next rung, twice; the line comes from the third worker
+    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "hang", "ZK_BENCH_RUNG_BUDGET_S": "10,10,60"}, "torch"),
     ({}, "native"),
 ])
 def test_bench_sharded_transports_one_rank(env_extra, want_transport):
@@ -59,6 +63,16 @@ def test_bench_sharded_transports_one_rank(env_extra, want_transport):
     rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
     assert rec["transport"] == want_transport and rec["parity_checked"] is True
     assert (rec["transport_note"] is not None) == ("ZK_BENCH_SIMULATE_NATIVE_FAILURE" in env_extra)
+    assert len([l for l in out.stdout.splitlines() if l.strip()]) == 1          # exactly one line, whatever the ladder did
+    lad = rec["ladder"]
+    assert lad["transport"] == want_transport and rec["shard"]["selftest_ok"] is True
+    if env_extra.get("ZK_BENCH_SIMULATE_NATIVE_FAILURE") == "hang":
+        assert lad["worker"] == 2 and lad["rung"] == 2 and "WATCHDOG" in out.stderr and lad["seconds_since_supervisor_start"] < 120
+    else:
+        assert lad["worker"] == 0
+    for k in ("exchange_ms", "exposed_exchange_ms", "tail_ms", "per_rank", "plan"):
+        assert k in rec["shard"], k
+    assert rec["shard"]["per_rank"][0]["rank"] == 0 and rec["shard"]["per_rank"][0]["exchanges"] > 0
     assert rec["shard"]["native_rccl"] == (1 if want_transport == "native" else 0)
     if want_transport == "native":
         assert rec["shard"]["rccl_nranks"] == 1
