@@ -116,6 +116,8 @@ RUNG_BUDGET_S = (50.0, 40.0, 40.0)     # rendezvous + communicator(s) + self-tes
 if os.environ.get("ZK_BENCH_RUNG_BUDGET_S"):                 # rehearsals shorten the deadlines (tests/test_bench_cli.py)
     RUNG_BUDGET_S = tuple(float(x) for x in os.environ["ZK_BENCH_RUNG_BUDGET_S"].split(","))
 RUN_BUDGET_S = 150.0                   # everything after the first proof (timed steps, secondary legs, parity proof)
+RENDEZVOUS_BUDGET_S = 150.0            # gloo rendezvous of the workers: no RCCL in it, but the ranks' first `import torch` on a fresh
+                                       # box can finish a minute apart, and a rank that gives up early would split the generations
 SHARD_TIMEOUT_S = 20.0                 # zk_shard_options.timeout_s: every host-side wait on a peer inside the library
 
 
@@ -149,13 +151,14 @@ def supervise():
                 return 0
             try:
                 with open(status) as f:
-                    last = int(f.read().strip() or rung)
+                    last = int(f.read().strip())
             except (OSError, ValueError):
-                last = rung
+                last = rung - 1                               # died before it could say anything: the same rung again
             # 3: not enough GPUs, 4: a proof that differs (parity): nothing another transport would change
             if code in (3, 4) or os.environ.get("ZK_BENCH_STAGED") == "1" or last + 1 >= len(LADDER):
                 return code if code > 0 else 1
-            print(f"[bench] rank {rank}: worker exited with {code} on rung {last} ({LADDER[last][0]}{' + plain' if LADDER[last][1] else ''}) after "
+            where = f"rung {last} ({LADDER[last][0]}{' + plain' if LADDER[last][1] else ''})" if last >= 0 else "the rendezvous"
+            print(f"[bench] rank {rank}: worker exited with {code} on {where} after "
                   f"{time.time() - t_start:.0f} s; starting a fresh worker on rung {last + 1}", file=sys.stderr, flush=True)
             rung = last + 1
             attempt += 1
@@ -339,17 +342,22 @@ def main():
         import datetime
         wd = Watchdog(rank)
         start_rung = int(os.environ.get("ZK_BENCH_RUNG", "0"))
-        wd.arm(RUNG_BUDGET_S[min(start_rung, len(RUNG_BUDGET_S) - 1)], "rendezvous of the control plane (gloo)")
+        if os.environ.get("ZK_BENCH_STATUS"):                 # a worker that dies before its first rung is retried on the SAME rung
+            with open(os.environ["ZK_BENCH_STATUS"], "w") as f:
+                f.write(str(start_rung - 1))
+        wd.arm(RENDEZVOUS_BUDGET_S, "rendezvous of the control plane (gloo)")
         # control plane only (unique id broadcast, agreement rounds, max over ranks of the time): gloo on the host, one
         # rendezvous file per worker generation (no port to collide with a previous generation's).  The data path is RCCL
         # inside the library (zk_shard_*: grouped ncclSend/ncclRecv all-to-all, ncclAllGather).
         store = os.environ.get("ZK_BENCH_STORE")
         if store:
-            dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+            dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=RENDEZVOUS_BUDGET_S))
         else:
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
                 os.environ.setdefault(k, v)
             dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))
+        dist.barrier()                                        # every rank is here: the rung deadlines start together
 
     def barrier():
         if dist.is_initialized():
