@@ -245,6 +245,10 @@ def test_shard_plan_is_the_one_layout(zk):
     assert pl["sharded_layers"] == 5 and pl["tail_rounds"] == 1
     pl = zk.shard_plan(2, 9, 3, min_layer_log=1, min_chunk_log=3, overlap_min_log=3)
     assert pl["chunked_mask"] & 1 and pl["piece_log"][0] == 10 and not (pl["chunked_mask"] >> 2) & 1
+    # zk_shard_options.plain_collectives (the fall-back rung of bench.py): the same distributed layers, nothing in chunks
+    pl = zk.shard_plan(8, 24, 3, plain_collectives=True)
+    assert pl["sharded_layers"] == 6 and pl["chunked_mask"] == 0 and pl["chunked_layers"] == 0 and pl["overlap_min_log"] == 99
+    assert pl["all_to_all_bytes"] == zk.shard_plan(8, 24, 3)["all_to_all_bytes"]
     for bad in ((3, 12, 3), (16, 12, 3), (2, 3, 3), (4, 4, 2)):
         with pytest.raises(zk.ZkError) as e:
             zk.shard_plan(*bad)
@@ -283,3 +287,21 @@ def test_host_hash_mode_follows_the_cpu(zk):
     finally:
         lib.zk_host_set_hash_mode(2)
     assert zk.host_hash_mode() == names[want]
+
+
+def test_tuning_surface_is_calls_not_environment(zk):
+    """Round 4 froze the tuning surface: the library reads two operational environment variables,
+    everything else is a documented call, an option field or a build-time constant.  The setters that need no GPU are
+    exercised here; the source is checked for stray getenv calls."""
+    import re
+    lib = zk.load()
+    assert lib.zk_dev_set_merkle_latency_log(11) == -1 and lib.zk_dev_set_merkle_latency_log(25) == -1
+    assert lib.zk_dev_set_merkle_latency_log(16) == 0 and lib.zk_dev_set_merkle_latency_log(0) == 0      # 0 = the build's default
+    names = set()
+    csrc = os.path.join(ROOT, "zkstark_amd", "csrc")
+    for fn in os.listdir(csrc):
+        with open(os.path.join(csrc, fn)) as f:
+            names |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', f.read()))
+    assert names == {"ZK_HOST_TIMING", "ZK_SHARD_TIMEOUT_S"}, names
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert all(n in doc for n in names)

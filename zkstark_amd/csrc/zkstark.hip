@@ -516,7 +516,7 @@ uint32_t zk_field_pow(uint32_t a, uint32_t e) { return powmod(a, e); }
 uint32_t zk_field_from_u32(uint32_t v) { return v % P; }
 // field.rs:52-86 Gf::generator(): the first x >= 2 with x^((P-1)/q) != 1 for every prime factor q of P - 1.  Searched as the
 // reference searches it (unique prime factors by trial division, then candidates in order), once; the kernels use the
-// constant GEN_W, which this search must -- and does -- return (5; tests/test_cabi.py pins it against the oracle's search).
+// constant GEN_W, which this search must -- and does -- return (5; pinned by tests/test_cabi.py).
 uint32_t zk_field_generator(void) {
     static const uint32_t g = [] {
         uint32_t factors[32], nf = 0, p = P - 1;
