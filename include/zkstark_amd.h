@@ -441,8 +441,8 @@ int zk_ntt_host(int device, uint32_t *data, uint32_t log_m, int inverse);
 int zk_lde_host(int device, const uint32_t *trace, uint32_t log_n, uint32_t log_blowup, uint32_t *out);
 
 /* ---- coset domains and device-pointer primitives (stream-ordered) ------------------
- * For callers that own the device buffers and the orchestration (the multi-GPU prover in
- * zkstark_amd/sharded.py drives these between RCCL collectives).  A domain is
+ * For callers that own the device buffers and the orchestration (the sharded prover, csrc/shard.hip,
+ * drives these between RCCL collectives).  A domain is
  * {shift * h^i, i < 2^(log_n+log_blowup)}, h = zk_field_root_of_unity(log_n+log_blowup), with
  * the tables the kernels need; the reference's domain is shift = 5 (prover.rs:69).  log_blowup
  * may be 0.  fold_only != 0 builds only what zk_dev_fri_fold needs.  Entry points that take only device

@@ -125,6 +125,14 @@ int dom_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, bool fo
     d->gm3_mont = to_mont(mulmod(mulmod(gm1, gm1), gm1));
     d->ninv_mont = to_mont(invmod((uint32_t)(d->n % P)));
     d->inv2_mont = to_mont(invmod(2));
+    {
+        const uint32_t inv2 = invmod(2);
+        uint32_t wr = shift;                                     // w^(2^r)
+        for (uint32_t r = 0; r < d->L && r < 32; ++r) { d->fold_k[r] = mulmod(invmod(wr), inv2); wr = mulmod(wr, wr); }
+        uint32_t xn = powmod(shift, d->n);                       // x^n on the domain takes B values: shift^n (h^n)^(i mod B)
+        const uint32_t hn = powmod(d->h, d->n);
+        for (size_t r = 0; r < d->B; ++r) { const uint32_t den = sub(xn, 1); d->inv_den[r] = den ? invmod(den) : 0u; xn = mulmod(xn, hn); }
+    }
     if (!fold_only) {
         if ((rc = build_table(shift, log_n, &d->W))) { dom_free(d); return rc; }
         // x_i - 1 must be invertible on the whole domain: shift^N != 1
@@ -200,13 +208,9 @@ int compose_args(const zk_dom* d, const uint32_t* d_f, uint32_t* d_cp, uint32_t 
     uint32_t a0 = alpha_raw[0] % P, a1 = alpha_raw[1] % P, a2 = alpha_raw[2] % P;   // field.rs:20-24
     a.alpha0_mont = to_mont(a0);
     a.alpha1g2_mont = to_mont(mulmod(a1, mulmod(d->g, d->g)));
-    // x^n on the domain takes B values: (shift h^i)^n = shift^n (h^n)^(i mod B)
-    uint32_t xn = powmod(d->shift, d->n), hn = powmod(d->h, d->n);
     for (size_t r = 0; r < d->B; ++r) {
-        uint32_t den = sub(xn, 1);
-        if (den == 0) return fail(ZK_ERR_INVALID, "compose: x^n = 1 on the domain");
-        a.zz[r] = to_mont(to_mont(mulmod(a2, invmod(den))));
-        xn = mulmod(xn, hn);
+        if (d->inv_den[r] == 0) return fail(ZK_ERR_INVALID, "compose: x^n = 1 on the domain");
+        a.zz[r] = to_mont(to_mont(mulmod(a2, d->inv_den[r])));
     }
     return ZK_OK;
 }
@@ -227,8 +231,7 @@ int fold_args(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t l
     a.in = d_in; a.out = d_out; a.log_m = log_m; a.round = round;
     a.hinv = d->Hinv.view(); a.L = d->L;
     a.inv2_mont = d->inv2_mont;
-    uint32_t winv = invmod(powmod(d->shift, (uint64_t)1 << round));
-    a.c_mont = to_mont(mulmod(mulmod(beta_raw % P, winv), invmod(2)));
+    a.c_mont = to_mont(mulmod(beta_raw % P, d->fold_k[round]));   // beta * w^(-2^r) / 2
     return ZK_OK;
 }
 int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t log_m, uint32_t round, uint32_t beta_raw,

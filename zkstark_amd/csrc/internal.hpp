@@ -93,6 +93,10 @@ struct zk_dom {
     uint32_t* d_inv_xm1 = nullptr;   // null for fold-only domains
     zk::impl::Plan plan;
     uint32_t shift_mont = 0, gm1_mont = 0, gm2_mont = 0, gm3_mont = 0, ninv_mont = 0, inv2_mont = 0;
+    // challenge-independent factors of the per-round constants, computed once (they sat on the commit -> challenge -> launch
+    // path of every round: two modular exponentiations per fold, B inversions per composition)
+    uint32_t fold_k[32] = {0};       // w^(-2^r) / 2, r < L                    (FoldArgs.c_mont = beta * fold_k[r])
+    uint32_t inv_den[32] = {0};      // 1 / (x^n - 1) for the B values x^n takes (ComposeArgs.zz[r] = alpha2 * inv_den[r]); 0: not invertible
     size_t device_bytes = 0;
 };
 

@@ -691,7 +691,7 @@ int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]) {
 
 // The layout of a sharded proof as a pure function of (world, sizes, options): which FRI layers stay distributed,
 // which of them are exchanged in chunks, and the bytes every rank sends to its peers.  zk_shard_create uses it, and so
-// does the torch.distributed mirror (zkstark_amd/sharded.py), so the two cannot drift apart.  No GPU needed.
+// does the test mirror (tests/sharded_mirror.py), so the two cannot drift apart.  No GPU needed.
 int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_options* opt, zk_shard_plan_info* out) {
     if (!out) return fail(ZK_ERR_INVALID, "zk_shard_plan: out is null");
     memset(out, 0, sizeof *out);

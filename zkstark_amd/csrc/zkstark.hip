@@ -76,6 +76,7 @@ struct zk_ctx {
     bool tail_have = false;             // false: the current FRI layer lives on the device only
     double t_wait = 0, t_host_hash = 0, t_launch = 0;   // ZK_HOST_TIMING: where the host thread spends a proof
     bool tail = false;                  // FRI-tail context (zk_tail_*): no trace / LDE / composition
+    uint32_t hinv_host = 0;             // 1 / h (the host-side FRI rounds step through its powers)
     uint32_t queries = 1;               // decommitment queries (1 = the reference, prover.rs:263)
     int hash = 0;                       // Merkle hash: 0 = SHA-256 (reference), 1 = field-native (configs[4])
     // opt-in reference self-checks (zk_ctx_set_checks; prover.rs:64-66, :148-159, :169, :228-251)
@@ -253,9 +254,8 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     uint32_t* nodes = stage_alloc(c, (2 * half - 1) * 8);
     if (!vals || !nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
     const zk_dom* d = c->dom;
-    const uint32_t inv2 = invmod(2);
-    const uint32_t cc_m = to_mont(mulmod(mulmod(beta_raw % P, invmod(powmod(d->shift, (uint64_t)1 << round))), inv2));   // beta / (2 w^(2^r))
-    const uint32_t step_m = to_mont(powmod(invmod(d->h), (uint64_t)1 << round));                                        // h^(-2^r)
+    const uint32_t cc_m = to_mont(mulmod(beta_raw % P, d->fold_k[round]));                  // beta / (2 w^(2^r))
+    const uint32_t step_m = to_mont(powmod(c->hinv_host, (uint64_t)1 << round));            // h^(-2^r)
     const uint32_t* in = c->tail_vals.data();
     uint32_t xinv_m = to_mont(1);                         // Montgomery form, like the device tables: canonical * Montgomery = canonical
     for (size_t i = 0; i < half; ++i) {
@@ -590,6 +590,7 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if ((rc = dom_make(device, log_n, log_b, shift, tail, c->stream, &c->dom))) return bail(rc);
     c->tail = tail;
+    c->hinv_host = invmod(c->dom->h);
     c->device_bytes += c->dom->device_bytes;
     // layers: 0 = f_eval (N), 1 + r = FRI layer r (N >> r), r = 0 .. R
     size_t off = 0;
@@ -950,7 +951,7 @@ int zk_compute_root_from_path(uint32_t element, size_t index, const uint8_t* pat
 
 // ---- FRI tail -----------------------------------------------------------------------
 // The last FRI layers of a proof whose earlier layers live elsewhere (the sharded prover hands
-// over once a layer is small enough to be replicated, zkstark_amd/sharded.py).  Layer rho0 of a
+// over once a layer is small enough to be replicated, shard.hip).  Layer rho0 of a
 // (log_n, log_b) proof is layer 0 of a domain with n' = n >> rho0 and shift w^(2^rho0), so the tail
 // is the ordinary fused fold + commit loop of prove_resident on that domain, driven by the caller's
 // channel.
