@@ -12,6 +12,7 @@ cp $O/bench_rehearsal_idfail.json $P/r04_bench_rehearsal_idfail.json; grep -E "^
 grep -v "amdgpu.ids" $O/batch_sizes.txt > $P/r04_batch_sizes.txt
 grep -v "amdgpu.ids" $O/config2_laps.txt > $P/r04_config2_laps.txt
 cp $O/shard_threads_timing.txt $P/r04_shard_threads_timing.txt
+grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" $O/soak.txt > $P/r04_soak.txt
 biggest() { ls -S $(find $1 -name "$2") | head -1; }      # a run may leave one file per process: the benchmark's is the large one
 cp $(biggest $O/prof_bench "*kernel_stats.csv") $P/r04_bench_2e24_kernel_stats.csv
 cp $(biggest $O/prof_field "*kernel_stats.csv") $P/r04_bench_2e24_fieldhash_kernel_stats.csv

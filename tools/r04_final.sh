@@ -30,6 +30,9 @@ ZK_BENCH_STAGED=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 -
 gcc -O2 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/shard_threads_check.c -Lzkstark_amd -lzkstark_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/zkstark_amd -Wl,-rpath,/opt/rocm/lib -o tools/shard_threads_check
 for w in "8 24" "4 23" "2 22"; do timeout -k 10 300 ./tools/shard_threads_check $w 3 0 0 0 3 2>&1 | grep -E "timing|threads ok" >> $O/shard_threads_timing.txt; done
 for s in "10 3" "14 3" "17 3"; do timeout -k 10 300 python tools/batch_bench.py $s >> $O/batch_sizes.txt 2>&1; done
+timeout -k 10 200 python tools/soak.py 40 > $O/soak.txt 2>&1; echo "soak rc=$?" | tee -a $O/soak.txt
+timeout -k 10 300 python tools/shard_soak.py 2 14 200 >> $O/soak.txt 2>&1; echo "shard soak rc=$?" | tee -a $O/soak.txt
+timeout -k 10 300 python tools/shard_rccl_soak.py 16 300 >> $O/soak.txt 2>&1; echo "rccl soak rc=$?" | tee -a $O/soak.txt
 find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
 timeout -k 10 1150 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -4 $O/pytest.log
 echo done

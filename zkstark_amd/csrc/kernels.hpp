@@ -25,7 +25,7 @@ enum KernelClass : int {
 
 constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
 constexpr double kShaInnerOps = 2293.0;
-constexpr double kNttOpsPerElement = 78.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU: 2456-2560 per wave of 32 elements/lane)
+constexpr double kNttOpsPerElement = 57.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU, round 4: 904.5 per wave of 16 elements/lane; round 3: 78)
 // field-native hash: one permutation per hash.  SQ_INSTS_VALU per wave of the subtree kernel's leaf launch (16 leaf + 15
 // inner hashes) and inner launch (7 inner hashes), solved for the two (profiles/r03_pmc/); the chain probe's loop body is
 // 9 092 by ISA count (tools/kernel_descriptors.py --loops), 9 103 by the counter
