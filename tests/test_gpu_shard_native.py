@@ -177,7 +177,7 @@ def _worker(rank, world, port, log_n, log_b, opts, q, mode, uid):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    __import__("mp_util").init_pg("gloo", port, rank, world)
     try:
         import zkstark_amd as zk
         from sharded_testlib import gloo_transport
@@ -203,10 +203,14 @@ def _run(world, log_n, log_b, opts, mode, timeout=900):
     uid = os.urandom(128)                                  # names the shared-memory root board (no RCCL here)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").fresh_store(port)
     procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, opts, q, mode, uid)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted((q.get(timeout=timeout) for _ in range(world)), key=lambda t: t[0])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mp_util import gather_results
+    out = sorted(gather_results(q, procs, world, timeout), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

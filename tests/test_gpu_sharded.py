@@ -38,7 +38,7 @@ def _worker(rank, world, port, log_n, log_b, q, lat):
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    __import__("mp_util").init_pg("gloo", port, rank, world)
     try:
         import zkstark_amd as zk
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -61,10 +61,14 @@ def test_sharded_multirank_one_gpu(orc, world, log_n, log_b, lat):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").fresh_store(port)
     procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, q, lat)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=600) for _ in range(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mp_util import gather_results, fresh_store
+    out = sorted(gather_results(q, procs, world, 600))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -120,7 +124,8 @@ def _nccl_worker(port, log_n, log_b, q):
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").init_pg("nccl", port, 0, 1, device_id=torch.device("cuda", 0))
     try:
         import zkstark_amd as zk
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -144,9 +149,13 @@ def test_sharded_collectives_over_rccl_single_rank(orc):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").fresh_store(port)
     p = ctx.Process(target=_nccl_worker, args=(port, 12, 3, q))
     p.start()
-    data, state = q.get(timeout=600)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mp_util import gather_results, fresh_store
+    data, state = gather_results(q, [p], 1, 600)[0]
     p.join(timeout=120)
     assert p.exitcode == 0
     assert data == want.proof and state == want.state
@@ -154,11 +163,12 @@ def test_sharded_collectives_over_rccl_single_rank(orc):
 
 def _config4_worker(rank, world, port, log_n, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    __import__("mp_util").init_pg("gloo", port, rank, world)
     try:
         import zkstark_amd as zk
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -186,10 +196,14 @@ def test_config4_sharded_lde_and_transpose_domain_2e26(zk, config4_expected):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mctx = mp.get_context("spawn")
     q = mctx.Queue()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").fresh_store(port)
     procs = [mctx.Process(target=_config4_worker, args=(r, world, port, log_n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=900) for _ in range(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mp_util import gather_results, fresh_store
+    out = sorted(gather_results(q, procs, world, 900))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

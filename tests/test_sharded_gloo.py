@@ -29,7 +29,7 @@ def _worker(rank, world, port, log_n, log_b, min_chunk_log, q, min_layer_log=Non
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    __import__("mp_util").init_pg("gloo", port, rank, world)
     try:
         import oracle
         from sharded_testlib import OracleBackend
@@ -53,10 +53,14 @@ def _run(world, log_n, log_b, min_chunk_log, min_layer_log=None, use_board=True)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").fresh_store(port)
     procs = [ctx.Process(target=_worker, args=(r, world, port, log_n, log_b, min_chunk_log, q, min_layer_log, use_board)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=300) for _ in range(world)]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mp_util import gather_results
+    out = gather_results(q, procs, world, 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -104,7 +108,7 @@ def _chunk_worker(rank, world, port, log_n, log_b, lists, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    __import__("mp_util").init_pg("gloo", port, rank, world)
     try:
         import oracle
         from sharded_testlib import ChunkingOracleBackend
@@ -129,10 +133,14 @@ def test_chunked_exchange_multirank(orc, world, log_n, log_b, lists):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    __import__("mp_util").fresh_store(port)
     procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, log_n, log_b, lists, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=300) for _ in range(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mp_util import gather_results
+    out = sorted(gather_results(q, procs, world, 300))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
