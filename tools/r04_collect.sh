@@ -13,6 +13,14 @@ grep -v "amdgpu.ids" $O/batch_sizes.txt > $P/r04_batch_sizes.txt
 grep -v "amdgpu.ids" $O/config2_laps.txt > $P/r04_config2_laps.txt
 cp $O/shard_threads_timing.txt $P/r04_shard_threads_timing.txt
 grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" $O/soak.txt > $P/r04_soak.txt
+# gpurun MERGES a session's files into the local directory, which may still hold those of an earlier session: drop everything
+# older than 25 minutes before the newest file first
+python3 - <<PY
+import os
+files = [os.path.join(d, f) for d, _, fs in os.walk("$O") for f in fs]
+newest = max(os.path.getmtime(f) for f in files)
+[os.unlink(f) for f in files if os.path.getmtime(f) < newest - 25 * 60]
+PY
 biggest() { ls -S $(find $1 -name "$2") | head -1; }      # a run may leave one file per process: the benchmark's is the large one
 cp $(biggest $O/prof_bench "*kernel_stats.csv") $P/r04_bench_2e24_kernel_stats.csv
 cp $(biggest $O/prof_field "*kernel_stats.csv") $P/r04_bench_2e24_fieldhash_kernel_stats.csv
