@@ -361,9 +361,10 @@ def test_merkle_index_and_path_api(zk, orc):
             ctx.merkle_node(0, 2047)
 
 
-@pytest.mark.parametrize("q", [2, 7])
+@pytest.mark.parametrize("q", [2, 7, 64])
 def test_prover_multi_query(zk, orc, q):
-    """q decommitment queries: proof bytes equal to the oracle's, strict verifier accepts."""
+    """q decommitment queries: proof bytes equal to the oracle's, strict verifier accepts.
+    (q = 7 and 64: the decommitment launch runs with several workgroups, the last of which raises the flag.)"""
     try:
         orc.set_queries(q)
         want = orc.prove(10, 3, want_vectors=False)

@@ -169,6 +169,16 @@ ZK_SHA_TARGET void compress_ni(uint32_t* st, const uint32_t* blk) {
     rounds_msg(s0, s1, m);
     store_state(st, s0, s1);
 }
+ZK_SHA_TARGET void blocks_ni(uint32_t* st, const uint8_t* data, size_t blocks) {
+    const __m128i be = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);   // bytes of each 32-bit word reversed
+    __m128i s0, s1, m[4];
+    load_state(st, s0, s1);
+    for (; blocks; --blocks, data += 64) {
+        for (int i = 0; i < 4; ++i) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(data + 16 * i)), be);
+        rounds_msg(s0, s1, m);
+    }
+    store_state(st, s0, s1);
+}
 ZK_SHA_TARGET void leaf_ni(uint32_t v, uint32_t* out) {
     __m128i s0, s1, m[4];
     load_state(IV, s0, s1);
@@ -333,6 +343,16 @@ void host_sha_use_wide(bool on) {
 void host_sha_compress(uint32_t state[8], const uint32_t block[16]) {
     if (g_have_sha) compress_ni(state, block);
     else compress_generic(state, block);
+}
+
+void host_sha_blocks(uint32_t state[8], const uint8_t* data, size_t blocks) {
+    if (g_have_sha) { blocks_ni(state, data, blocks); return; }
+    for (; blocks; --blocks, data += 64) {
+        uint32_t w[16];
+        for (int i = 0; i < 16; ++i)
+            w[i] = ((uint32_t)data[4 * i] << 24) | ((uint32_t)data[4 * i + 1] << 16) | ((uint32_t)data[4 * i + 2] << 8) | data[4 * i + 3];
+        compress_generic(state, w);
+    }
 }
 
 void host_sha_leaf(uint32_t v, uint32_t out[8]) {

@@ -22,6 +22,9 @@ bool host_sha_wide_available();
 void host_sha_use_wide(bool on);
 // one compression of a 64-byte block given as sixteen big-endian-decoded words (transcript hashing)
 void host_sha_compress(uint32_t state[8], const uint32_t block[16]);
+// `blocks` consecutive 64-byte blocks of a byte stream (transcript hashing: the state stays in registers from block to
+// block and the big-endian decoding is one byte shuffle per 16 bytes)
+void host_sha_blocks(uint32_t state[8], const uint8_t* data, size_t blocks);
 // out = SHA256(be32(v)) as state words (merkle.rs:30-34)
 void host_sha_leaf(uint32_t v, uint32_t out[8]);
 // out[8 i ..] = SHA256(be32(vals[i])) for i < n

@@ -319,24 +319,36 @@ hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uin
 //   cp = alpha0 p0 + alpha1 p1 + alpha2 p2
 // with f(g x_i) = f[i+B], f(g^2 x_i) = f[i+2B] (indices mod N); x^n - 1 depends on i mod B only.
 // BATCH: f and the trace / challenge constants belong to one proof of a batch, and a.zz carries no alpha2.
-template <bool BATCH>
-__device__ __forceinline__ uint32_t compose_core(const ComposeArgs& a, const uint32_t* f, uint32_t first, uint32_t last, uint32_t al0,
-                                                 uint32_t al1g2, uint32_t al2, size_t i) {
+struct ComposeRaw { uint32_t f0, f1, f2, inv0, inv2, x_hi, x_lo, zz; };
+__device__ __forceinline__ ComposeRaw compose_fetch(const ComposeArgs& a, const uint32_t* f, size_t i) {
     const size_t N = (size_t)1 << a.logN;
     const uint32_t B = 1u << a.log_b;
     const size_t i1 = (i + B) & (N - 1), i2 = (i + 2 * (size_t)B) & (N - 1);
-    uint32_t f0 = f[i], f1 = f[i1], f2 = f[i2];
-    uint32_t inv0 = a.inv_xm1[i], inv2 = a.inv_xm1[i2];
-    uint32_t x = mont_mul(pow_lookup(a.htab, (uint32_t)i), a.w_mont);           // Montgomery x_i
-    uint32_t t0 = mont_mul(mont_mul(sub(f0, first), inv0), al0);
-    uint32_t t1 = mont_mul(mont_mul(sub(f0, last), inv2), al1g2);
+    ComposeRaw r;
+    r.f0 = f[i]; r.f1 = f[i1]; r.f2 = f[i2];
+    r.inv0 = a.inv_xm1[i]; r.inv2 = a.inv_xm1[i2];
+    r.x_hi = a.htab.hi[(uint32_t)i >> a.htab.lo_bits]; r.x_lo = a.htab.lo[(uint32_t)i & ((1u << a.htab.lo_bits) - 1u)];   // pow_lookup's two halves
+    r.zz = a.zz[i & (B - 1)];
+    return r;
+}
+template <bool BATCH>
+__device__ __forceinline__ uint32_t compose_finish(const ComposeArgs& a, const ComposeRaw& r, uint32_t first, uint32_t last, uint32_t al0,
+                                                   uint32_t al1g2, uint32_t al2) {
+    uint32_t x = mont_mul(mont_mul(r.x_hi, r.x_lo), a.w_mont);                    // Montgomery x_i
+    uint32_t t0 = mont_mul(mont_mul(sub(r.f0, first), r.inv0), al0);
+    uint32_t t1 = mont_mul(mont_mul(sub(r.f0, last), r.inv2), al1g2);
     uint32_t v3 = mont_mul(mont_mul(sub(x, a.gm3_mont), sub(x, a.gm2_mont)), sub(x, a.gm1_mont));   // V*R
-    uint32_t y = mont_mul(v3, a.zz[i & (B - 1)]);                                // alpha2 V / (x^n-1) * R^2
+    uint32_t y = mont_mul(v3, r.zz);                                             // alpha2 V / (x^n-1) * R^2
     if (BATCH) y = mont_mul(y, al2);
     // data*data products carry R^-1; bring f2 to the same scale, fix with the R^2 in y
-    uint32_t num = sub(sub(mont_mul(f2, 1u), mont_mul(f1, f1)), mont_mul(f0, f0));
+    uint32_t num = sub(sub(mont_mul(r.f2, 1u), mont_mul(r.f1, r.f1)), mont_mul(r.f0, r.f0));
     uint32_t t2 = mont_mul(num, y);
     return add(add(t0, t1), t2);
+}
+template <bool BATCH>
+__device__ __forceinline__ uint32_t compose_core(const ComposeArgs& a, const uint32_t* f, uint32_t first, uint32_t last, uint32_t al0,
+                                                 uint32_t al1g2, uint32_t al2, size_t i) {
+    return compose_finish<BATCH>(a, compose_fetch(a, f, i), first, last, al0, al1g2, al2);
 }
 __device__ __forceinline__ uint32_t compose_at(const ComposeArgs& a, size_t i) {
     return compose_core<false>(a, a.f, a.first, a.last, a.alpha0_mont, a.alpha1g2_mont, 0u, i);
@@ -361,14 +373,22 @@ hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof) {
 // ===========================================================================
 // next[i] = (e[i] + e[i+m/2])/2 + beta (e[i] - e[i+m/2]) / (2 x_i),  x_i = (w h^i)^(2^r)
 // (identity pinned by fri_test, polynomial.rs:418-425, and used at proof.rs:110-113).
-__device__ __forceinline__ uint32_t fold_at(const FoldArgs& a, size_t i) {
+struct FoldRaw { uint32_t u, v, x_hi, x_lo; };
+__device__ __forceinline__ FoldRaw fold_fetch(const FoldArgs& a, size_t i) {
     const size_t half = (size_t)1 << (a.log_m - 1);
-    uint32_t u = a.in[i], v = a.in[i + half];
-    uint32_t xinv = pow_lookup(a.hinv, (uint32_t)(i << a.round));   // h^(-2^r i), i 2^r < N/2
-    uint32_t s = mont_mul(add(u, v), a.inv2_mont);
-    uint32_t d = mont_mul(mont_mul(sub(u, v), xinv), a.c_mont);
+    const uint32_t e = (uint32_t)(i << a.round);                    // h^(-2^r i), i 2^r < N/2
+    FoldRaw r;
+    r.u = a.in[i]; r.v = a.in[i + half];
+    r.x_hi = a.hinv.hi[e >> a.hinv.lo_bits]; r.x_lo = a.hinv.lo[e & ((1u << a.hinv.lo_bits) - 1u)];
+    return r;
+}
+__device__ __forceinline__ uint32_t fold_finish(const FoldArgs& a, const FoldRaw& r) {
+    uint32_t xinv = mont_mul(r.x_hi, r.x_lo);
+    uint32_t s = mont_mul(add(r.u, r.v), a.inv2_mont);
+    uint32_t d = mont_mul(mont_mul(sub(r.u, r.v), xinv), a.c_mont);
     return add(s, d);
 }
+__device__ __forceinline__ uint32_t fold_at(const FoldArgs& a, size_t i) { return fold_finish(a, fold_fetch(a, i)); }
 
 __global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -415,22 +435,38 @@ template <> struct Hasher<1> {
 // Where the leaf values of a tree come from.  The prover fuses the elementwise producer of a layer
 // into the leaf hashing of its commitment: the value is computed, written to the layer and hashed
 // in one pass (no separate fold / compose launch, the layer is never re-read for hashing).
+// A source is read in two steps so that the throughput kernel can have the memory reads of its NEXT group of 64 leaves
+// in flight while it hashes the current one: fetch() only issues loads (what they return is `Raw`), finish() does the
+// arithmetic and the store of the produced value.  load() = both, for the callers that take one value at a time.
 struct PlainSrc {
     const uint32_t* vals;
+    using Raw = uint32_t;
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return vals[pos]; }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return r; }
     __device__ __forceinline__ uint32_t load(size_t pos) const { return vals[pos]; }
 };
 struct FoldSrc {       // FRI layer r+1 = fold(layer r, beta): prover.rs:198-211 + :214
     FoldArgs a;
-    __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = fold_at(a, pos); a.out[pos] = v; return v; }
+    using Raw = FoldRaw;
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return fold_fetch(a, pos); }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t pos) const { uint32_t v = fold_finish(a, r); a.out[pos] = v; return v; }
+    __device__ __forceinline__ uint32_t load(size_t pos) const { return finish(fetch(pos), pos); }
 };
 struct ComposeSrc {    // cp layer 0 from f_eval: prover.rs:101-173 + :176
     ComposeArgs a;
+    using Raw = size_t;        // nothing fetched ahead: eight words in flight per lane cost more registers than the 2^24-leaf
+                               // launch (four waves per SIMD hide the latency) gains -- measured 1 579 against 1 560 us
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return pos; }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return load(r); }
     __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = compose_at(a, pos); a.cp[pos] = v; return v; }
 };
 
 struct ComposeBatchSrc {   // batch of proofs: leaf b*N + i = cp_b[i], with proof b's own challenges
     ComposeArgs a;
     const BatchChal* chal;
+    using Raw = size_t;        // batched trees run with the chip full: nothing fetched ahead
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return pos; }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return load(r); }
     __device__ __forceinline__ uint32_t load(size_t pos) const {
         const size_t b = pos >> a.logN, i = pos & (((size_t)1 << a.logN) - 1);
         const BatchChal c = chal[b];
@@ -442,6 +478,9 @@ struct ComposeBatchSrc {   // batch of proofs: leaf b*N + i = cp_b[i], with proo
 struct FoldBatchSrc {      // leaf b*(m/2) + i = fold of proof b's layer with its own beta
     FoldArgs a;
     const BatchChal* chal;
+    using Raw = size_t;
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return pos; }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return load(r); }
     __device__ __forceinline__ uint32_t load(size_t pos) const {
         const uint32_t lh = a.log_m - 1;
         const size_t half = (size_t)1 << lh, b = pos >> lh, i = pos & (half - 1);
@@ -459,9 +498,12 @@ struct FoldBatchSrc {      // leaf b*(m/2) + i = fold of proof b's layer with it
 struct InterleaveSrc { // leaves arrive as 2^log_parts cyclic pieces of 2^log_cnt words (multi-GPU all-to-all output):
     const uint32_t* recv;  // leaf u*parts + q = recv[q*cnt + u]; hashed straight from the receive buffer
     uint32_t log_parts, log_cnt;
+    using Raw = uint32_t;
     __device__ __forceinline__ uint32_t load(size_t pos) const {
         return recv[((pos & (((size_t)1 << log_parts) - 1)) << log_cnt) | (pos >> log_parts)];
     }
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return load(pos); }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return r; }
 };
 
 constexpr int kMerkleThreads = 256;
@@ -507,15 +549,27 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
     const size_t in_base = ((size_t)1 << depth_in) - 1;
     uint4* my = stage + (size_t)wave * (k + 1) * 128;
     uint4* scratch = my + (size_t)k * 128;
+    // The reads of group i + 1 are issued before group i is hashed (a wave that meets its load latency at the top of
+    // every group stalls 2^k times, and with two waves per SIMD running the same code in step, both at once), and
+    // they are consumed -- SRC::finish: the producer's arithmetic and the store of its value -- at the END of group i,
+    // behind that group's digest stores: the wait in front of finish() then leaves those stores in flight.
+    typename SRC::Raw raw;
+    Digest dnext;
+    uint32_t val = 0;
+    if (LEAF) val = src.load(base + lane - off);                 // the source is chunk-local
+    else dnext = load_digest(nodes, in_base + base + lane);
 #pragma unroll 1
     for (uint32_t i = 0; i < (1u << k); ++i) {
         Digest d;
         const size_t pos = base + (size_t)i * 64 + lane;         // 64 consecutive inputs: coalesced
+        const bool more = i + 1 < (1u << k);                     // wave-uniform
         if (LEAF) {
-            d = Hasher<HASH>::leaf(src.load(pos - off));      // the source is chunk-local
+            if (more) raw = src.fetch(pos + 64 - off);
+            d = Hasher<HASH>::leaf(val);
             store_digest(nodes, in_base + pos, d);
         } else {
-            d = load_digest(nodes, in_base + pos);
+            d = dnext;
+            if (more) dnext = load_digest(nodes, in_base + pos + 64);
         }
         uint32_t idx = i, lvl = 0;
 #pragma unroll 1
@@ -536,6 +590,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
             ++lvl;
             store_digest(nodes, (((size_t)1 << (depth_in - lvl)) - 1) + (base >> lvl) + (size_t)idx * 64 + lane, d);
         }
+        if (LEAF && more) val = src.finish(raw, pos + 64 - off);
     }
 }
 
@@ -566,16 +621,30 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     const size_t in_base = ((size_t)1 << depth_in) - 1;
     QuadLane ql;
     if (HASH == 0) ql = quad_lane(tid);
+    // a thread takes up to 2^kWgMaxLog / kWgThreads = 4 inputs: every read is issued before the first one is used (one
+    // load latency per launch instead of one per input; this phase is a chain of latencies)
+    constexpr uint32_t kPer = (1u << kWgMaxLog) / kWgThreads;
+    if (LEAF) {
+        typename SRC::Raw raw[kPer] = {};
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if (tid + u * kWgThreads < cnt) raw[u] = src.fetch(first + tid + u * kWgThreads - off);
 #pragma unroll 1
-    for (uint32_t i = tid; i < cnt; i += kWgThreads) {
-        Digest d;
-        if (LEAF) {
-            d = Hasher<HASH>::leaf(src.load(first + i - off));
+        for (uint32_t i = tid; i < cnt; i += kWgThreads) {          // one copy of the hash: the fetched inputs move up
+            const Digest d = Hasher<HASH>::leaf(src.finish(raw[0], first + i - off));
             store_digest(nodes, in_base + first + i, d);
-        } else {
-            d = load_digest(nodes, in_base + first + i);
+            lds_store(&lvl[2 * i], d);
+#pragma unroll
+            for (uint32_t u = 0; u + 1 < kPer; ++u) raw[u] = raw[u + 1];
         }
-        lds_store(&lvl[2 * i], d);
+    } else {
+        Digest dd[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if (tid + u * kWgThreads < cnt) dd[u] = load_digest(nodes, in_base + first + tid + u * kWgThreads);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if (tid + u * kWgThreads < cnt) lds_store(&lvl[2 * (tid + u * kWgThreads)], dd[u]);
     }
     // the layer values this workgroup produced are read by ANOTHER workgroup (the one that finishes last) when
     // they are posted to the host: make every wave's stores visible device-wide, not only the posting wave's
@@ -1075,6 +1144,44 @@ hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t 
     ScopedKernelTimer tm(prof, K_GATHER, 8.0 * (double)count * words, s);
     uint32_t total = count * words, blocks = (total + 255) / 256;
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, src, offsets, count, words, out);
+    return hipGetLastError();
+}
+
+
+// One launch for a whole decommitment: work list and results in host-mapped memory, flag behind the results.
+constexpr int kFetchThreads = 1024;
+__global__ __launch_bounds__(kFetchThreads) void fetch_kernel(const uint32_t* layers, const uint32_t* trees, const uint64_t* items, uint32_t nv,
+                                                              uint32_t ndg, uint32_t* out, uint32_t* mailbox, uint32_t seq, uint32_t* counter) {
+    const uint32_t stride = gridDim.x * kFetchThreads;
+    for (uint32_t idx = blockIdx.x * kFetchThreads + threadIdx.x; idx < 2 * ndg + nv; idx += stride) {
+        if (idx < 2 * ndg) {                                      // half a node per thread: 16-byte accesses on both sides
+            const uint4* src = reinterpret_cast<const uint4*>(trees + items[nv + (idx >> 1)]);
+            reinterpret_cast<uint4*>(out)[idx] = src[idx & 1u];
+        } else {
+            const uint32_t i = idx - 2 * ndg;
+            out[8 * (size_t)ndg + i] = layers[items[i]];
+        }
+    }
+    __threadfence_system();                                       // this thread's results are in host memory ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool last = true;
+        if (gridDim.x > 1) {                                      // ... and so are everybody else's
+            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(&mailbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_fetch(const uint32_t* layers, const uint32_t* trees, const uint64_t* items, uint32_t nv, uint32_t ndg, uint32_t* out,
+                        uint32_t* mailbox, uint32_t seq, uint32_t* counter, hipStream_t s, Profiler* prof) {
+    ScopedKernelTimer tm(prof, K_GATHER, 8.0 * ((double)nv + 8.0 * (double)ndg), s);
+    const uint32_t work = 2 * ndg + nv;
+    uint32_t blocks = (work + kFetchThreads - 1) / kFetchThreads;
+    if (blocks == 0) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(fetch_kernel, dim3(blocks), dim3(kFetchThreads), 0, s, layers, trees, items, nv, ndg, out, mailbox, seq, counter);
     return hipGetLastError();
 }
 

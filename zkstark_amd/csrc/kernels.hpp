@@ -246,5 +246,11 @@ hipError_t launch_hash_chain_probe(int hash, uint32_t blocks, uint32_t* out, uin
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,
                          uint32_t* out, hipStream_t s, Profiler* prof = nullptr);
+// Decommitment read-out without copy commands (the one-call prover): `nv` values of `layers` and `ndg` 8-word nodes of
+// `trees`, word offsets in `items` (values first), which lies in host-mapped memory like `out`: out[8 j ..] = node j,
+// out[8 ndg + i] = value i.  The workgroup that finishes last raises mailbox[0] = seq behind the results (counter: one
+// zeroed device word, as in MailArgs); the host polls instead of synchronising the stream.
+hipError_t launch_fetch(const uint32_t* layers, const uint32_t* trees, const uint64_t* items, uint32_t nv, uint32_t ndg, uint32_t* out,
+                        uint32_t* mailbox, uint32_t seq, uint32_t* counter, hipStream_t s, Profiler* prof = nullptr);
 
 }  // namespace zk

@@ -147,21 +147,23 @@ struct Sha256 {
     size_t fill = 0;
     uint64_t total = 0;
     Sha256() { for (int i = 0; i < 8; ++i) st[i] = SHA_IV[i]; }
-    void block(const uint8_t* p) {
-        uint32_t w[16];
-        for (int i = 0; i < 16; ++i)
-            w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
-        host_sha_compress(st, w);                  // SHA extensions when the CPU has them (host_sha.cpp)
-    }
     void update(const void* data, size_t n) {
         const uint8_t* m = (const uint8_t*)data;
         total += n;
-        while (n) {
-            size_t take = 64 - fill < n ? 64 - fill : n;
+        if (fill) {
+            const size_t take = 64 - fill < n ? 64 - fill : n;
             memcpy(buf + fill, m, take);
             fill += take; m += take; n -= take;
-            if (fill == 64) { block(buf); fill = 0; }
+            if (fill < 64) return;
+            host_sha_blocks(st, buf, 1);               // SHA extensions when the CPU has them (host_sha.cpp)
+            fill = 0;
         }
+        if (n >= 64) {                                 // whole blocks straight from the caller's bytes
+            host_sha_blocks(st, m, n / 64);
+            m += n & ~(size_t)63; n &= 63;
+        }
+        memcpy(buf, m, n);
+        fill = n;
     }
     void finalize(uint8_t out[32]) {
         uint64_t bits = total * 8;

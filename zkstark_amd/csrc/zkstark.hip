@@ -51,8 +51,19 @@ struct zk_ctx {
     std::vector<size_t> tree_off;
     uint64_t* d_gather_off = nullptr;
     uint32_t* d_gather_out = nullptr;
-    uint64_t* h_gather_off = nullptr;   // pinned
-    uint32_t* h_gather_out = nullptr;   // pinned
+    uint64_t* h_gather_off = nullptr;   // pinned, device-mapped (dm_*: the device's view): the one-call prover's decommitment
+    uint32_t* h_gather_out = nullptr;   // launch reads its work list and writes its results there (launch_fetch)
+    uint64_t* dm_gather_off = nullptr;
+    uint32_t* dm_gather_out = nullptr;
+    // what this thread built during the current proof and still holds in the staging buffer: nodes [0, host_node_cnt) of
+    // a tree (its top, or all of it), a whole small layer.  The decommitment reads those from there.
+    const uint32_t* host_nodes[40] = {};
+    size_t host_node_cnt[40] = {};
+    const uint32_t* host_vals[40] = {};
+    std::vector<const uint32_t*> fetch_vals, fetch_nodes;
+    std::vector<uint32_t> fetch_vdev;
+    std::vector<uint64_t> fetch_ditems;
+    std::vector<uint8_t> commit_buf;
     uint32_t* h_small = nullptr;        // pinned: root words + last layer
     uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: layout in kernels.hpp (MailArgs)
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
@@ -241,6 +252,8 @@ int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
     if (c->tail_have && c->tail_log == layer_log(c, tree) && tree >= 1) {     // this launch dumped its leaves (mail_of)
         c->tail_vals.assign(c->h_mailbox + kMailValsOff, c->h_mailbox + kMailValsOff + ((size_t)1 << c->tail_log));
     }
+    c->host_nodes[tree] = nodes;
+    c->host_node_cnt[tree] = 2 * cnt - 1;                 // the posted digests of depth H included
     return stage_seg(c, nodes, c->tree_off[tree], (cnt - 1) * 8, 0);
 }
 
@@ -269,6 +282,9 @@ int host_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     c->tail_vals.assign(vals, vals + half);
     c->tail_log = log_out;
     c->t_host_hash += now_us() - t_begin;
+    c->host_vals[2 + round] = vals;
+    c->host_nodes[2 + round] = nodes;
+    c->host_node_cnt[2 + round] = 2 * half - 1;
     int rc = stage_seg(c, vals, c->layer_off[2 + round], half, 1);
     if (!rc) rc = stage_seg(c, nodes, c->tree_off[2 + round], (2 * half - 1) * 8, 0);
     return rc;
@@ -283,6 +299,9 @@ int fri_round_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
 void begin_proof(zk_ctx* c) {
     c->stage_used = 0; c->n_segs = 0; c->seg_words = 0; c->tail_log = 0; c->tail_have = false;
     c->t_wait = c->t_host_hash = c->t_launch = 0;
+    memset(c->host_nodes, 0, sizeof c->host_nodes);
+    memset(c->host_node_cnt, 0, sizeof c->host_node_cnt);
+    memset(c->host_vals, 0, sizeof c->host_vals);
 }
 // Device copies of everything the host built, stream-ordered before any later read of trees / layers.
 int flush_host_parts(zk_ctx* c) {
@@ -437,53 +456,78 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     for (uint32_t k = 0; k < Q; ++k) qraws[k] = ch.get_u32();   // prover.rs:263 (x Q)
     c->info.query_raw = qraws[0];
 
-    // decommit (prover.rs:266-289): one gather for the values, one for the path digests, all queries
-    std::vector<uint64_t> voff, doff;
-    std::vector<size_t> nodes;
-    auto add_path = [&](uint32_t tree, size_t m, size_t leaf) {
-        nodes.clear();
-        path_nodes(m, leaf, nodes);
-        for (size_t nd : nodes) doff.push_back((uint64_t)c->tree_off[tree] + (uint64_t)nd * 8);
+    // decommit (prover.rs:266-289).  Values and path nodes this thread built itself during the proof (tree tops, the small
+    // FRI layers and their trees) are still in the staging buffer and are read from there; everything else comes back
+    // through ONE launch that takes its work list from host-mapped memory, writes its results there and raises the
+    // mailbox flag behind them: no copy commands, no stream synchronisation.  The scatter that completes the device
+    // arrays with the host-built parts is enqueued behind it, off the proof's critical path.
+    const size_t nvals = (size_t)Q * (4 + 2 * R);
+    std::vector<const uint32_t*>& vsrc = c->fetch_vals;
+    std::vector<const uint32_t*>& dsrc = c->fetch_nodes;
+    std::vector<uint32_t>& vdev = c->fetch_vdev;
+    std::vector<uint64_t>& ditems = c->fetch_ditems;
+    vsrc.assign(nvals, nullptr); vdev.assign(nvals, 0); dsrc.clear(); ditems.clear();
+    uint64_t* items = c->h_gather_off;
+    size_t nv = 0, ndg = 0, vi = 0;
+    auto want_val = [&](uint32_t layer, size_t x) {
+        if (c->host_vals[layer]) vsrc[vi++] = c->host_vals[layer] + x;
+        else { vdev[vi++] = (uint32_t)nv; items[nv++] = (uint64_t)c->layer_off[layer] + x; }
+    };
+    auto want_path = [&](uint32_t tree, size_t m, size_t leaf) {       // merkle.rs:54-71: the sibling at every depth
+        for (size_t i = leaf + m - 1; i != 0; i = (i - 1) >> 1) {
+            const size_t nd = (i & 1) ? i + 1 : i - 1;
+            if (nd < c->host_node_cnt[tree]) dsrc.push_back(c->host_nodes[tree] + 8 * nd);
+            else { dsrc.push_back(c->h_gather_out + 8 * ndg); ++ndg; ditems.push_back((uint64_t)c->tree_off[tree] + (uint64_t)nd * 8); }
+        }
     };
     for (uint32_t k = 0; k < Q; ++k) {
         const size_t x = (size_t)qraws[k] % (N - 2 * B);
-        voff.push_back(c->layer_off[0] + x);         add_path(0, N, x);
-        voff.push_back(c->layer_off[0] + x + B);     add_path(0, N, x + B);
-        voff.push_back(c->layer_off[0] + x + 2 * B); add_path(0, N, x + 2 * B);
-        voff.push_back(c->layer_off[1] + x);         add_path(1, N, x);
+        want_val(0, x);         want_path(0, N, x);
+        want_val(0, x + B);     want_path(0, N, x + B);
+        want_val(0, x + 2 * B); want_path(0, N, x + 2 * B);
+        want_val(1, x);         want_path(1, N, x);
         for (uint32_t i = 0; i < R; ++i) {
             size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
-            voff.push_back(c->layer_off[1 + i] + xi); add_path(1 + i, len, xi);
-            voff.push_back(c->layer_off[1 + i] + nx); add_path(1 + i, len, nx);
+            want_val(1 + i, xi); want_path(1 + i, len, xi);
+            want_val(1 + i, nx); want_path(1 + i, len, nx);
         }
     }
-    const size_t nv = voff.size(), ndg = doff.size();
     if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
-    {
-        memcpy(c->h_gather_off, voff.data(), nv * 8);
-        memcpy(c->h_gather_off + nv, doff.data(), ndg * 8);
-        HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, (nv + ndg) * 8, hipMemcpyHostToDevice, c->stream));
-        if ((rc = flush_host_parts(c))) return rc;
-        HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream, prof_of(c)));
-        HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream, prof_of(c)));
-        HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    lap("free term + gather enqueue");
-    HIPCHK(hipStreamSynchronize(c->stream));
-    lap("gather wait");
-    std::vector<uint8_t> dig(ndg * 32);
-    for (size_t i = 0; i < ndg; ++i) digest_words_to_bytes(c->h_gather_out + nv + 8 * i, dig.data() + 32 * i);
-    const uint32_t* vals = c->h_gather_out;
+    if (ndg) memcpy(items + nv, ditems.data(), ndg * 8);
+    for (size_t i = 0; i < nvals; ++i)
+        if (!vsrc[i]) vsrc[i] = c->h_gather_out + 8 * ndg + vdev[i];
+    const bool fetch = nv + ndg != 0;
+    if (fetch) HIPCHK(launch_fetch(c->d_layers, c->d_trees, c->dm_gather_off, (uint32_t)nv, (uint32_t)ndg, c->dm_gather_out, c->d_mailbox,
+                                   ++c->mail_seq, c->d_counter, c->stream, prof_of(c)));
+    if ((rc = flush_host_parts(c))) return rc;
+    lap("free term + fetch enqueue");
+    if (fetch && (rc = wait_mail(c))) return rc;
+    lap("fetch wait");
     const size_t Lp = c->L;
+    std::vector<uint8_t>& buf = c->commit_buf;
+    buf.resize(8 + 2 * (8 + 32 * Lp));
+    auto put32 = [](uint8_t* p, uint32_t v) { for (int i = 0; i < 4; ++i) p[i] = (uint8_t)(v >> (8 * i)); };
+    auto put_path = [&](uint8_t* p, size_t first, size_t plen) {       // Box<[Hash]>: u64 count + items
+        for (int i = 0; i < 8; ++i) p[i] = (uint8_t)((uint64_t)plen >> (8 * i));
+        for (size_t j = 0; j < plen; ++j) digest_words_to_bytes(dsrc[first + j], p + 8 + 32 * j);
+        return 8 + 32 * plen;
+    };
     size_t dpos = 0;
-    for (uint32_t q = 0; q < Q; ++q, vals += 4 + 2 * R) {
-        for (int k = 0; k < 4; ++k) {                         // prover.rs:274-277
-            ch.commit_val_path(vals[k], dig.data() + 32 * dpos, Lp);
+    vi = 0;
+    for (uint32_t q = 0; q < Q; ++q) {
+        for (int k = 0; k < 4; ++k) {                         // (u32, AuthPath): prover.rs:274-277
+            put32(buf.data(), *vsrc[vi++]);
+            const size_t len = 4 + put_path(buf.data() + 4, dpos, Lp);
+            ch.commit_bytes(buf.data(), len);
             dpos += Lp;
         }
-        for (uint32_t i = 0; i < R; ++i) {                    // prover.rs:280-289
-            size_t pl = Lp - i;
-            ch.commit_pair_paths(vals[4 + 2 * i], vals[5 + 2 * i], dig.data() + 32 * dpos, dig.data() + 32 * (dpos + pl), pl);
+        for (uint32_t i = 0; i < R; ++i) {                    // (u32, u32, AuthPath, AuthPath): prover.rs:280-289
+            const size_t pl = Lp - i;
+            put32(buf.data(), *vsrc[vi]); put32(buf.data() + 4, *vsrc[vi + 1]);
+            vi += 2;
+            size_t len = 8 + put_path(buf.data() + 8, dpos, pl);
+            len += put_path(buf.data() + len, dpos + pl, pl);
+            ch.commit_bytes(buf.data(), len);
             dpos += 2 * pl;
         }
     }
@@ -613,8 +657,10 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     c->gather_cap = (size_t)kMaxQueries * (4 + 2 * c->R) * (c->L + 1) + 64;
     if ((rc = dmalloc(c, &c->d_gather_off, c->gather_cap * 8))) return bail(rc);
     if ((rc = dmalloc(c, &c->d_gather_out, c->gather_cap * 32))) return bail(rc);
-    HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8));
-    HIPCHK_C(hipHostMalloc((void**)&c->h_gather_out, c->gather_cap * 32));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_gather_off, c->gather_cap * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_gather_out, c->gather_cap * 32, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_C(hipHostGetDevicePointer((void**)&c->dm_gather_off, c->h_gather_off, 0));
+    HIPCHK_C(hipHostGetDevicePointer((void**)&c->dm_gather_out, c->h_gather_out, 0));
     HIPCHK_C(hipHostMalloc((void**)&c->h_small, 4096));
     const size_t mail_bytes = kMailWords * 4;
     if ((rc = dmalloc(c, &c->d_counter, 64))) return bail(rc);
