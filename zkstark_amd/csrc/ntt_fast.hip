@@ -83,6 +83,10 @@ __device__ __forceinline__ void dft_regs(uint32_t (&x)[1 << LOG]) {
 __device__ __forceinline__ uint32_t pow_lookup(const PowTable& t, uint32_t e) {
     return mont_mul(t.hi[e >> t.lo_bits], t.lo[e & ((1u << t.lo_bits) - 1u)]);
 }
+// the two table reads of pow_lookup, issued where the exponent is known; the product is taken where it is needed
+struct PowRaw { uint32_t hi, lo; };
+__device__ __forceinline__ PowRaw pow_fetch(const PowTable& t, uint32_t e) { return PowRaw{t.hi[e >> t.lo_bits], t.lo[e & ((1u << t.lo_bits) - 1u)]}; }
+__device__ __forceinline__ uint32_t pow_of(const PowRaw& r) { return mont_mul(r.hi, r.lo); }
 
 // Raw buffer over [base, base + 4 GiB): word at base + lane_off + row_off (bytes; lane_off in a VGPR, row_off uniform).
 // An arrays of this library has at most 2^30 words, so every offset fits 32 bits; out-of-range reads return 0.
@@ -130,6 +134,37 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     const uint32_t smask = (1u << logS) - 1u;
     const uint32_t tw_shift = p.L - LOGR - logS;
 
+    // A small transform runs one or two workgroups per compute unit, and a pass is then a chain of memory round trips
+    // (twiddle tables, data, twiddles of the second step): every read whose address is known here is issued here, so
+    // that they all wait together.  (RB * C == kThreads for every tile in use: a thread has ONE step-1 item.)
+    constexpr bool ONE = RB * C == kThreads;
+    constexpr bool PRELOAD = ONE && !STAGED && !LDE;
+    constexpr int IT2 = (RA * C + kThreads - 1) / kThreads;   // RA*C < kThreads (small tile, R = 256): half the threads idle in step 2
+    uint32_t xpre[RA];
+    PowRaw pre_cur{}, pre_step{}, post_cur[IT2], post_step[IT2];
+    if (ONE) {
+        const uint32_t c = tid & (C - 1), tb = tid >> LOGC;
+        if (PRELOAD) {
+            const uint32_t off = (tb << (logS + 2)) + (c << 2);
+            const Rsrc b = make_rsrc(p.src + (((size_t)(col0 >> logS) << (LOGR + logS)) + (col0 & smask)));
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) xpre[ta] = ld_b(b, off, in_sgpr((uint32_t)(ta * RB) << (logS + 2)));
+        }
+        if (MODE != NTT_DIF && logS) {
+            const uint32_t s1 = (col0 + c) & smask;
+            pre_cur = pow_fetch(p.tw, (tb * s1) << tw_shift);
+            pre_step = pow_fetch(p.tw, ((uint32_t)RB * s1) << tw_shift);
+        }
+    }
+    if (MODE == NTT_DIF && logS) {
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const uint32_t q = tid + it * kThreads;
+            const uint32_t s2 = (col0 + (q & (C - 1))) & smask, ka = (q >> LOGC) & (RA - 1);
+            post_cur[it] = pow_fetch(p.tw, (ka * s2) << tw_shift);
+            post_step[it] = pow_fetch(p.tw, ((uint32_t)RA * s2) << tw_shift);
+        }
+    }
     for (uint32_t e = tid; e < (uint32_t)R; e += kThreads) twl[e] = pow_lookup(p.tw, e << (p.L - LOGR));
 
     // Non-staged tiles (S >= C) lie inside one block `a` of the [A][R][S] view: element (row t, column c) of the tile is
@@ -219,6 +254,9 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
         } else if (STAGED) {
 #pragma unroll
             for (int ta = 0; ta < RA; ++ta) x[ta] = tile[(ta * RB + tb) * PITCH + c];
+        } else if (PRELOAD) {
+#pragma unroll
+            for (int ta = 0; ta < RA; ++ta) x[ta] = xpre[ta];
         } else {
             const uint32_t off = (tb << row_sh) + (c << 2);
 #pragma unroll
@@ -226,8 +264,8 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
         }
         if (MODE != NTT_DIF && logS) {
             // pre-twiddle w_{RS}^(t*s), t = ta*Rb + tb: running product over ta
-            uint32_t cur = pow_lookup(p.tw, (tb * s) << tw_shift);
-            const uint32_t step = pow_lookup(p.tw, ((uint32_t)RB * s) << tw_shift);
+            uint32_t cur = ONE ? pow_of(pre_cur) : pow_lookup(p.tw, (tb * s) << tw_shift);
+            const uint32_t step = ONE ? pow_of(pre_step) : pow_lookup(p.tw, ((uint32_t)RB * s) << tw_shift);
 #pragma unroll
             for (int ta = 0; ta < RA; ++ta) {
                 x[ta] = mont_mul(x[ta], cur);
@@ -248,7 +286,6 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     __syncthreads();
 
     // ---- step 2: Rb-point DFTs over tb (consecutive rows) ----------------------------------
-    constexpr int IT2 = (RA * C + kThreads - 1) / kThreads;   // RA*C < kThreads (small tile, R = 256): half the threads idle here
     constexpr bool TO_LDS = STAGED || LDE;                     // contiguous destination tile: stores go through LDS
     uint32_t keep[IT2][RB];   // staged stores wait until every thread has read the tile
 #pragma unroll
@@ -256,7 +293,6 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
         const uint32_t q = tid + it * kThreads;
         if (RA * C < kThreads && q >= (uint32_t)(RA * C)) continue;
         const uint32_t c = q & (C - 1), ka = q >> LOGC;
-        const uint32_t s = (col0 + c) & smask;
         uint32_t (&y)[RB] = keep[it];
 #pragma unroll
         for (int tb = 0; tb < RB; ++tb) y[tb] = tile[(ka * RB + tb) * PITCH + c];
@@ -264,8 +300,8 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
         if (MODE == NTT_DIF) {
             if (logS) {
                 // post-twiddle w_{RS}^(k*s), k = ka + Ra*kb: running product over kb
-                uint32_t cur = pow_lookup(p.tw, (ka * s) << tw_shift);
-                const uint32_t step = pow_lookup(p.tw, ((uint32_t)RA * s) << tw_shift);
+                uint32_t cur = pow_of(post_cur[it]);
+                const uint32_t step = pow_of(post_step[it]);
 #pragma unroll
                 for (int kb = 0; kb < RB; ++kb) {
                     const int i = c_brev(kb, LB);
