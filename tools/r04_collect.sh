@@ -11,6 +11,8 @@ cp $O/bench_rehearsal_hang.json $P/r04_bench_rehearsal_hang.json; grep -E "^\[be
 cp $O/bench_rehearsal_idfail.json $P/r04_bench_rehearsal_idfail.json; grep -E "^\[bench\]" $O/bench_rehearsal_idfail.err > $P/r04_bench_rehearsal_idfail.log || true
 grep -v "amdgpu.ids" $O/batch_sizes.txt > $P/r04_batch_sizes.txt
 grep -v "amdgpu.ids" $O/config2_laps.txt > $P/r04_config2_laps.txt
+grep "zk timing" $O/proof_laps.txt | tail -12 > $P/r04_proof_laps.txt
+grep "LDE + Merkle commit" $O/config2_warmup.txt > $P/r04_config2_warmup_final.txt
 cp $O/shard_threads_timing.txt $P/r04_shard_threads_timing.txt
 grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" $O/soak.txt > $P/r04_soak.txt
 # gpurun MERGES a session's files into the local directory, which may still hold those of an earlier session: drop everything

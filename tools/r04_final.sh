@@ -11,6 +11,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_staged -- python3 bench.py --staged-only > $O/prof_staged.log 2>&1
 ZK_HOST_TIMING=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg2 -- python3 tools/config2_only.py 17 20 > $O/prof_cfg2.log 2>&1
 ZK_HOST_TIMING=1 timeout -k 10 120 python tools/config2_only.py 17 20 > $O/config2_laps.txt 2>&1
+ZK_HOST_TIMING=1 timeout -k 10 120 python tools/host_timing.py 21 > $O/proof_laps.txt 2>&1
+for r in 50 500 5000 50; do timeout -k 10 120 python tools/config2_only.py 17 $r >> $O/config2_warmup.txt 2>&1; done
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_staged -- python3 bench.py --staged-only > $O/pmc_fetch_staged.log 2>&1
