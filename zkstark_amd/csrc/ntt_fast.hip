@@ -286,6 +286,13 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
     __syncthreads();
 
     // ---- step 2: Rb-point DFTs over tb (consecutive rows) ----------------------------------
+#ifndef ZK_NTT_LDE_DIRECT
+#define ZK_NTT_LDE_DIRECT 1
+#endif
+    // The first LDE pass writes rows of S = B words: B >= 8 makes them whole 32-byte sectors, which go straight to HBM
+    // like the rows of a non-staged pass instead of through the LDS tile (two barriers and two LDS sweeps less: 36.4 ->
+    // 33.3 us at N = 2^24, profiles/r04_ab_ntt_lde.txt; ZK_BUILD_DEFS="-DZK_NTT_LDE_DIRECT=0" is the other side of that A/B).
+    const bool lde_direct = ZK_NTT_LDE_DIRECT && LDE && logS >= 3;
     constexpr bool TO_LDS = STAGED || LDE;                     // contiguous destination tile: stores go through LDS
     uint32_t keep[IT2][RB];   // staged stores wait until every thread has read the tile
 #pragma unroll
@@ -317,9 +324,14 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_fast_kernel(NttPassArgs p) 
             const uint32_t off = (ka << row_sh) + (c << 2);
 #pragma unroll
             for (int i = 0; i < RB; ++i) st_b(dstb, off, in_sgpr((uint32_t)(RA * c_brev(i, LB)) << row_sh), y[i]);
+        } else if (ZK_NTT_LDE_DIRECT && LDE && lde_direct) {
+            // column c of the tile = block a = c >> logS, position s = c & smask of the [A][R][S] view (col0 is a multiple of C >= S)
+            const uint32_t off = ((c >> logS) << (LOGR + logS + 2)) + (ka << row_sh) + ((c & smask) << 2);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) st_b(tdst, off, in_sgpr((uint32_t)(RA * c_brev(i, LB)) << row_sh), y[i]);
         }
     }
-    if (TO_LDS) {
+    if (TO_LDS && !lde_direct) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
