@@ -15,15 +15,16 @@ grep "zk timing" $O/proof_laps.txt | tail -12 > $P/r04_proof_laps.txt
 grep "LDE + Merkle commit" $O/config2_warmup.txt > $P/r04_config2_warmup_final.txt
 cp $O/shard_threads_timing.txt $P/r04_shard_threads_timing.txt
 grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" $O/soak.txt > $P/r04_soak.txt
-# gpurun MERGES a session's files into the local directory, which may still hold those of an earlier session: drop everything
-# older than 25 minutes before the newest file first
-python3 - <<PY
-import os
-files = [os.path.join(d, f) for d, _, fs in os.walk("$O") for f in fs]
+# gpurun MERGES a session's files into the local directory, which may still hold those of an earlier session (same names
+# apart from the process id): of the files matching, take the biggest one among those written within 3 minutes of the newest
+# (a run may leave one file per process: the benchmark's is the large one)
+biggest() { python3 - "$1" "$2" <<'PY'
+import fnmatch, os, sys
+files = [os.path.join(d, f) for d, _, fs in os.walk(sys.argv[1]) for f in fs if fnmatch.fnmatch(f, sys.argv[2])]
 newest = max(os.path.getmtime(f) for f in files)
-[os.unlink(f) for f in files if os.path.getmtime(f) < newest - 25 * 60]
+print(max((f for f in files if os.path.getmtime(f) >= newest - 180), key=os.path.getsize))
 PY
-biggest() { ls -S $(find $1 -name "$2") | head -1; }      # a run may leave one file per process: the benchmark's is the large one
+}
 cp $(biggest $O/prof_bench "*kernel_stats.csv") $P/r04_bench_2e24_kernel_stats.csv
 cp $(biggest $O/prof_field "*kernel_stats.csv") $P/r04_bench_2e24_fieldhash_kernel_stats.csv
 cp $(biggest $O/prof_staged "*kernel_stats.csv") $P/r04_staged_2e24_kernel_stats.csv
