@@ -1,6 +1,6 @@
 // Prints digests from csrc/host_sha.cpp for tests/test_host_sha.py (compared there with hashlib).
 //   host_sha_check <ext: 0 portable | 1 SHA extensions, one or two nodes at a time | 2 + sixteen at a time (AVX-512F)> <depth> <seed>
-// prints "<sha extensions in use> <wide path in use>", the heap, the chain
+// prints "<sha extensions in use> <wide path in use>", the heap, the chain, the byte-stream chain
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -38,5 +38,13 @@ int main(int argc, char** argv) {
         zk::host_sha_compress(st, blk);
     }
     hex(st);
+    // the same through the byte-stream entry point (host_sha_blocks: several blocks per call, big-endian decoding inside):
+    // five blocks of LCG bytes, at an odd address, fed as 2 + 3
+    std::vector<uint8_t> bytes(5 * 64 + 1);
+    for (size_t i = 1; i < bytes.size(); ++i) { x = x * 1664525u + 1013904223u; bytes[i] = (uint8_t)(x >> 24); }
+    uint32_t s2[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    zk::host_sha_blocks(s2, bytes.data() + 1, 2);
+    zk::host_sha_blocks(s2, bytes.data() + 1 + 128, 3);
+    hex(s2);
     return 0;
 }
