@@ -331,19 +331,25 @@ __device__ __forceinline__ ComposeRaw compose_fetch(const ComposeArgs& a, const 
     r.zz = a.zz[i & (B - 1)];
     return r;
 }
+// one value of cp from its operands: f at the three taps, 1/(x - 1) at two, x itself (Montgomery), zz = alpha2 / (x^n - 1) R^2
+template <bool BATCH>
+__device__ __forceinline__ uint32_t compose_eval(const ComposeArgs& a, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t inv0, uint32_t inv2,
+                                                 uint32_t x, uint32_t zz, uint32_t first, uint32_t last, uint32_t al0, uint32_t al1g2, uint32_t al2) {
+    uint32_t t0 = mont_mul(mont_mul(sub(f0, first), inv0), al0);
+    uint32_t t1 = mont_mul(mont_mul(sub(f0, last), inv2), al1g2);
+    uint32_t v3 = mont_mul(mont_mul(sub(x, a.gm3_mont), sub(x, a.gm2_mont)), sub(x, a.gm1_mont));   // V*R
+    uint32_t y = mont_mul(v3, zz);                                               // alpha2 V / (x^n-1) * R^2
+    if (BATCH) y = mont_mul(y, al2);
+    // data*data products carry R^-1; bring f2 to the same scale, fix with the R^2 in y
+    uint32_t num = sub(sub(mont_mul(f2, 1u), mont_mul(f1, f1)), mont_mul(f0, f0));
+    uint32_t t2 = mont_mul(num, y);
+    return add(add(t0, t1), t2);
+}
 template <bool BATCH>
 __device__ __forceinline__ uint32_t compose_finish(const ComposeArgs& a, const ComposeRaw& r, uint32_t first, uint32_t last, uint32_t al0,
                                                    uint32_t al1g2, uint32_t al2) {
-    uint32_t x = mont_mul(mont_mul(r.x_hi, r.x_lo), a.w_mont);                    // Montgomery x_i
-    uint32_t t0 = mont_mul(mont_mul(sub(r.f0, first), r.inv0), al0);
-    uint32_t t1 = mont_mul(mont_mul(sub(r.f0, last), r.inv2), al1g2);
-    uint32_t v3 = mont_mul(mont_mul(sub(x, a.gm3_mont), sub(x, a.gm2_mont)), sub(x, a.gm1_mont));   // V*R
-    uint32_t y = mont_mul(v3, r.zz);                                             // alpha2 V / (x^n-1) * R^2
-    if (BATCH) y = mont_mul(y, al2);
-    // data*data products carry R^-1; bring f2 to the same scale, fix with the R^2 in y
-    uint32_t num = sub(sub(mont_mul(r.f2, 1u), mont_mul(r.f1, r.f1)), mont_mul(r.f0, r.f0));
-    uint32_t t2 = mont_mul(num, y);
-    return add(add(t0, t1), t2);
+    const uint32_t x = mont_mul(mont_mul(r.x_hi, r.x_lo), a.w_mont);              // Montgomery x_i
+    return compose_eval<BATCH>(a, r.f0, r.f1, r.f2, r.inv0, r.inv2, x, r.zz, first, last, al0, al1g2, al2);
 }
 template <bool BATCH>
 __device__ __forceinline__ uint32_t compose_core(const ComposeArgs& a, const uint32_t* f, uint32_t first, uint32_t last, uint32_t al0,
@@ -360,11 +366,62 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeArgs a) {
     a.cp[i] = compose_at(a, i);
 }
 
+// Four consecutive values per thread, 16-byte accesses (the stand-alone stage: HBM-bound, and one value per thread leaves
+// the memory system short of requests).  The taps i + B and i + 2B are whole vectors when B >= 4; for B = 1, 2 (the local
+// domains of a proof sharded over 8 or 4 GPUs) they are windows of the two vectors at i and i + 4.  x advances by h.
+__global__ __launch_bounds__(256) void compose_kernel4(ComposeArgs a) {
+    const size_t N = (size_t)1 << a.logN;
+    const uint32_t B = 1u << a.log_b;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= N) return;
+    const uint4* fv = reinterpret_cast<const uint4*>(a.f);
+    const uint4* iv = reinterpret_cast<const uint4*>(a.inv_xm1);
+    uint32_t f0[4], f1[4], f2[4], inv0[4], inv2[4], zz[4];
+    const uint4 v0 = fv[i >> 2], w0 = iv[i >> 2];
+    f0[0] = v0.x; f0[1] = v0.y; f0[2] = v0.z; f0[3] = v0.w;
+    inv0[0] = w0.x; inv0[1] = w0.y; inv0[2] = w0.z; inv0[3] = w0.w;
+    if (B >= 4) {
+        const uint4 v1 = fv[((i + B) & (N - 1)) >> 2], v2 = fv[((i + 2 * (size_t)B) & (N - 1)) >> 2], w2 = iv[((i + 2 * (size_t)B) & (N - 1)) >> 2];
+        f1[0] = v1.x; f1[1] = v1.y; f1[2] = v1.z; f1[3] = v1.w;
+        f2[0] = v2.x; f2[1] = v2.y; f2[2] = v2.z; f2[3] = v2.w;
+        inv2[0] = w2.x; inv2[1] = w2.y; inv2[2] = w2.z; inv2[3] = w2.w;
+        const uint32_t z0 = (uint32_t)i & (B - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) zz[k] = a.zz[z0 + k];
+    } else {
+        const uint4 v1 = fv[((i + 4) & (N - 1)) >> 2], w1 = iv[((i + 4) & (N - 1)) >> 2];
+        const uint32_t fw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const uint32_t iw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f1[k] = B == 1 ? fw[k + 1] : fw[k + 2];
+            f2[k] = B == 1 ? fw[k + 2] : fw[k + 4];
+            inv2[k] = B == 1 ? iw[k + 2] : iw[k + 4];
+            zz[k] = B == 1 ? a.zz[0] : a.zz[k & 1];
+        }
+    }
+    uint32_t x = mont_mul(pow_lookup(a.htab, (uint32_t)i), a.w_mont);
+    const uint32_t h = pow_lookup(a.htab, 1u);
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[k] = compose_eval<false>(a, f0[k], f1[k], f2[k], inv0[k], inv2[k], x, zz[k], a.first, a.last, a.alpha0_mont, a.alpha1g2_mont, 0u);
+        if (k < 3) x = mont_mul(x, h);
+    }
+    reinterpret_cast<uint4*>(a.cp)[i >> 2] = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof) {
     size_t N = (size_t)1 << a.logN;
     ScopedKernelTimer tm(prof, K_COMPOSE, 8.0 * (double)N, s);   // read f once, write cp once
-    uint32_t blocks = (uint32_t)((N + 255) / 256);
-    hipLaunchKernelGGL(compose_kernel, dim3(blocks), dim3(256), 0, s, a);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.f) | reinterpret_cast<uintptr_t>(a.inv_xm1) | reinterpret_cast<uintptr_t>(a.cp)) & 15u) == 0;
+    if (a.logN >= 4 && aligned) {
+        uint32_t blocks = (uint32_t)((N / 4 + 255) / 256);
+        hipLaunchKernelGGL(compose_kernel4, dim3(blocks), dim3(256), 0, s, a);
+    } else {
+        uint32_t blocks = (uint32_t)((N + 255) / 256);
+        hipLaunchKernelGGL(compose_kernel, dim3(blocks), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -396,11 +453,37 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a) {
     a.out[i] = fold_at(a, i);
 }
 
+// four consecutive outputs per thread, 16-byte accesses; x^-1 advances by h^(-2^r)
+__global__ __launch_bounds__(256) void fri_fold_kernel4(FoldArgs a) {
+    const size_t half = (size_t)1 << (a.log_m - 1);
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= half) return;
+    const uint4 u = reinterpret_cast<const uint4*>(a.in)[i >> 2], v = reinterpret_cast<const uint4*>(a.in)[(i + half) >> 2];
+    const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+    uint32_t xinv = pow_lookup(a.hinv, (uint32_t)(i << a.round));
+    const uint32_t step = pow_lookup(a.hinv, 1u << a.round);
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sm = mont_mul(add(uu[k], vv[k]), a.inv2_mont);
+        const uint32_t d = mont_mul(mont_mul(sub(uu[k], vv[k]), xinv), a.c_mont);
+        r[k] = add(sm, d);
+        if (k < 3) xinv = mont_mul(xinv, step);
+    }
+    reinterpret_cast<uint4*>(a.out)[i >> 2] = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
     size_t half = (size_t)1 << (a.log_m - 1);
     ScopedKernelTimer tm(prof, K_FOLD, 12.0 * (double)half, s);   // read m words, write m/2
-    uint32_t blocks = (uint32_t)((half + 255) / 256);
-    hipLaunchKernelGGL(fri_fold_kernel, dim3(blocks), dim3(256), 0, s, a);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15u) == 0;
+    if (half >= 4 && aligned) {
+        uint32_t blocks = (uint32_t)((half / 4 + 255) / 256);
+        hipLaunchKernelGGL(fri_fold_kernel4, dim3(blocks), dim3(256), 0, s, a);
+    } else {
+        uint32_t blocks = (uint32_t)((half + 255) / 256);
+        hipLaunchKernelGGL(fri_fold_kernel, dim3(blocks), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 
