@@ -386,21 +386,28 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
             const size_t cc = per >> lk;                          // words per (peer, chunk)
             HIPCHK(hipEventRecord(s->ev_layer, s->stream));
             HIPCHK(hipStreamWaitEvent(s->xstream, s->ev_layer, 0));
+            // A chunk build is ONE launch of exactly one round of workgroups: back to back on one stream every launch pays
+            // its own ramp-up and drain (4.61 instead of 4.08 ms of leaf hashing per proof at one rank).  Alternating
+            // between two streams lets the next chunk's workgroups take the CUs as the previous chunk's leave them.
+            // The build of chunk c is enqueued right behind ITS exchange (a host-staged transport blocks in the exchange:
+            // this way chunk c is hashed while chunk c + 1 travels).
+            const bool two = s->bstream != nullptr;
             for (uint32_t c = 0; c < K; ++c) {
                 for (int g = 0; g < G; ++g) {
                     send[g] = loc + (size_t)g * per + (size_t)c * cc;
                     recv[g] = s->d_recv + ((size_t)c * G + g) * cc;
                 }
-                if ((rc = all_to_all(s, send, recv, cc, s->xstream))) return rc;
-                HIPCHK(hipEventRecord(s->ev_chunk[c], s->xstream));
-            }
-            // A chunk build is ONE launch of exactly one round of workgroups: back to back on one stream every launch pays
-            // its own ramp-up and drain (4.61 instead of 4.08 ms of leaf hashing per proof at one rank).  Alternating
-            // between two streams lets the next chunk's workgroups take the CUs as the previous chunk's leave them.
-            const bool two = s->bstream != nullptr;
-            for (uint32_t c = 0; c < K; ++c) {
+                // Chunk 0 is the exposed one (nothing to hash beside it): its exchange goes to the MAIN stream, in order
+                // between the kernel that produced the layer and the build of the chunk.  On the exchange stream it sat
+                // behind two cross-queue event dependencies (layer -> exchange, exchange -> build), each of which the
+                // hardware resolves in 20-35 us (kernel trace of a one-rank proof: 70 us from the end of the producer to the
+                // start of the first build, of which the exchange itself is 17).  The other chunks keep the exchange stream:
+                // their dependencies resolve while the previous chunk is being hashed.
+                hipStream_t xs = c == 0 ? s->stream : s->xstream;
                 hipStream_t bs = (two && (c & 1u)) ? s->bstream : s->stream;
-                {
+                if ((rc = all_to_all(s, send, recv, cc, xs))) return rc;
+                if (xs != bs) {
+                    HIPCHK(hipEventRecord(s->ev_chunk[c], xs));
                     ScopedTimed stall(s, bs, 2);               // how long this hashing stream waits for chunk c's exchange
                     HIPCHK(hipStreamWaitEvent(bs, s->ev_chunk[c], 0));
                 }
