@@ -17,7 +17,7 @@ def test_bench_gpus_n_spawns_ranks_and_needs_n_gpus():
         pytest.skip("two GPUs present: this would run the real benchmark")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                         capture_output=True, text=True, timeout=600, env=env)
+                         capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode != 0
     assert "needs 2 GPUs" in out.stderr and "rank 1" in out.stderr        # the ranks WERE launched, then failed clearly
     assert out.stdout.strip() == ""                                       # no JSON line for an unmeasured run
@@ -30,7 +30,7 @@ def test_bench_n2_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["ZK_BENCH_STAGED"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--log-n", "17"], capture_output=True, text=True, timeout=900, env=env)
+                          "--log-n", "17"], capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -58,7 +58,7 @@ def test_bench_sharded_transports_one_rank(env_extra, want_transport):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(ZK_BENCH_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "16", "--no-secondary"],
-                         capture_output=True, text=True, timeout=900, env=env)
+                         capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
     assert rec["transport"] == want_transport and rec["parity_checked"] is True
@@ -85,7 +85,7 @@ def test_bench_strong_scaling_and_exact_config4_rehearsal():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["ZK_BENCH_STAGED"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-n", "17",
-                          "--scaling", "strong"], capture_output=True, text=True, timeout=1100, env=env)
+                          "--scaling", "strong"], capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
     assert rec["scaling"] == "strong" and rec["config"]["log_n"] == 17 and rec["config"]["domain"] == 1 << 20

@@ -197,7 +197,7 @@ def _worker(rank, world, port, log_n, log_b, opts, q, mode, uid):
         dist.destroy_process_group()
 
 
-def _run(world, log_n, log_b, opts, mode, timeout=900):
+def _run(world, log_n, log_b, opts, mode, timeout=240):
     import torch.multiprocessing as mp
     port = _free_port()
     uid = os.urandom(128)                                  # names the shared-memory root board (no RCCL here)
@@ -277,7 +277,7 @@ def test_shard_two_ranks_production_sizes_2e25(orc):
     log_n, world = 22, 2
     want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
     assert want.rc == 0
-    out = _run(world, log_n, 3, {}, "prove", timeout=1200)
+    out = _run(world, log_n, 3, {}, "prove", timeout=240)
     for rank, data, state, roots, st in out:
         assert data == want.proof and state == want.state, f"rank {rank}"
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
@@ -291,7 +291,7 @@ def test_shard_four_ranks_production_sizes_2e26(orc):
     log_n, world = 23, 4
     want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
     assert want.rc == 0
-    out = _run(world, log_n, 3, {}, "prove", timeout=1200)
+    out = _run(world, log_n, 3, {}, "prove", timeout=240)
     N = 1 << (log_n + 3)
     for rank, data, state, roots, st in out:
         assert data == want.proof and state == want.state, f"rank {rank}"
@@ -307,7 +307,7 @@ def test_config4_native_sharded_lde_transpose_commit_2e26(zk, config4_expected):
     CPU oracle's (orc.lde + orc.merkle_build), the shards are the oracle's values at i = rank (mod 2)."""
     log_n, world = config4_expected["log_n"], 2
     want_root, want_head = config4_expected["root"], config4_expected["head"]
-    out = _run(world, log_n, 3, {}, "lde_commit", timeout=1200)
+    out = _run(world, log_n, 3, {}, "lde_commit", timeout=240)
     for rank, root, again, head, st in out:
         assert root == want_root and again == want_root, f"rank {rank}"
         assert head == [int(want_head[rank + world * j]) for j in range(4)]
@@ -322,7 +322,7 @@ def test_shard_from_plain_c(tmp_path, orc):
     subprocess.check_call(["gcc", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "shard_c_abi.c"),
                            "-L" + os.path.join(ROOT, "zkstark_amd"), "-lzkstark_amd", "-Wl,-rpath," + os.path.join(ROOT, "zkstark_amd"), "-o", exe])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([exe, "1", "12", "3"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([exe, "1", "12", "3"], capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     want = orc.prove(12, 3, want_vectors=False)
     assert f"world 1: {len(want.proof)} proof bytes on every rank, equal to zk_prove" in out.stdout
@@ -353,7 +353,7 @@ def test_shard_ranks_as_threads_of_one_process(threads_check, orc, world, log_n,
     harness) and the oracle's."""
     import subprocess
     out = subprocess.run([threads_check, str(world), str(log_n), str(log_b)] + [str(t) for t in thresholds],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     want = orc.prove(log_n, log_b, want_vectors=False)
     assert f"threads ok: world {world}, {len(want.proof)} proof bytes on every rank equal zk_prove" in out.stdout
@@ -369,7 +369,7 @@ def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
     free, _ = torch.cuda.mem_get_info()
     if free < 80 * 10**9:
         pytest.skip("needs 80 GB of free device memory")
-    out = subprocess.run([threads_check, "8", "24", "3", "0", "0", "0"], capture_output=True, text=True, timeout=1100)
+    out = subprocess.run([threads_check, "8", "24", "3", "0", "0", "0"], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     from zkstark_amd import _lib
     plen = _lib.load().zk_proof_data_len(24, 3)

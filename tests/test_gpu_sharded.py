@@ -68,7 +68,7 @@ def test_sharded_multirank_one_gpu(orc, world, log_n, log_b, lat):
         p.start()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mp_util import gather_results, fresh_store
-    out = sorted(gather_results(q, procs, world, 600))
+    out = sorted(gather_results(q, procs, world, 240))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -155,7 +155,7 @@ def test_sharded_collectives_over_rccl_single_rank(orc):
     p.start()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mp_util import gather_results, fresh_store
-    data, state = gather_results(q, [p], 1, 600)[0]
+    data, state = gather_results(q, [p], 1, 240)[0]
     p.join(timeout=120)
     assert p.exitcode == 0
     assert data == want.proof and state == want.state
@@ -203,7 +203,7 @@ def test_config4_sharded_lde_and_transpose_domain_2e26(zk, config4_expected):
         p.start()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mp_util import gather_results, fresh_store
-    out = sorted(gather_results(q, procs, world, 900))
+    out = sorted(gather_results(q, procs, world, 240))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -60,7 +60,7 @@ def _run(world, log_n, log_b, min_chunk_log, min_layer_log=None, use_board=True)
         p.start()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mp_util import gather_results
-    out = gather_results(q, procs, world, 300)
+    out = gather_results(q, procs, world, 240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -140,7 +140,7 @@ def test_chunked_exchange_multirank(orc, world, log_n, log_b, lists):
         p.start()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mp_util import gather_results
-    out = sorted(gather_results(q, procs, world, 300))
+    out = sorted(gather_results(q, procs, world, 240))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
