@@ -78,6 +78,12 @@ uint32_t zk_field_neg(uint32_t a);                   /* field.rs:198-203 */
 uint32_t zk_field_inv(uint32_t a);                   /* field.rs:205-210 */
 uint32_t zk_field_pow(uint32_t a, uint32_t e);       /* field.rs:26-38 */
 uint32_t zk_field_from_u32(uint32_t v);              /* field.rs:20-24 */
+uint32_t zk_field_from_i32(int32_t v);               /* field.rs:10-18: v < 0 is -(|v| mod P) */
+/* field.rs:165-177: a * b^-1.  b = 0 (mod P): the reference panics; returns 0 and sets zk_last_error. */
+uint32_t zk_field_div(uint32_t a, uint32_t b);
+/* field.rs:89-94 Rem<u32>: (residue of a) % rhs as a field element.  rhs = 0: the reference panics; returns 0 and
+ * sets zk_last_error. */
+uint32_t zk_field_rem(uint32_t a, uint32_t rhs);
 uint32_t zk_field_generator(void);                   /* field.rs:52-86: the same search (first call), -> 5 */
 uint32_t zk_field_root_of_unity(uint32_t log_order); /* prover.rs:48-49 */
 uint32_t zk_field_order(uint32_t a);                 /* field.rs:45-49 (via P-1 = 3*2^30, not brute force) */

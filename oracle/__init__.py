@@ -16,16 +16,36 @@ P = 3221225473
 MODE_NTT, MODE_NAIVE = 0, 1
 
 
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("stark101_oracle.c", "stark101_oracle.h", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:24]
+
+
+def _stale():
+    try:
+        with open(_LIB_PATH + ".hash") as f:
+            return f.read().strip() != _source_hash()
+    except OSError:
+        return True
+
+
 def build(force=False):
-    """Compile liboracle.so with gcc (seconds).  An existing library is used as is unless force=True
-    (several test workers may import at once; a snapshot copy does not preserve mtimes)."""
-    if not force and os.path.exists(_LIB_PATH):
+    """Compile liboracle.so with gcc (seconds).  An existing library is used when it was built from the sources
+    in the tree (a hash beside it says so; several test workers may import at once, hence the lock)."""
+    if not force and os.path.exists(_LIB_PATH) and not _stale():
         return _LIB_PATH
     import fcntl
     with open(_LIB_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if force or not os.path.exists(_LIB_PATH):
+        if force or not os.path.exists(_LIB_PATH) or _stale():
             subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+            with open(_LIB_PATH + ".hash.tmp", "w") as f:
+                f.write(_source_hash() + "\n")
+            os.replace(_LIB_PATH + ".hash.tmp", _LIB_PATH + ".hash")
     return _LIB_PATH
 
 
@@ -69,6 +89,8 @@ def lib():
         L.orc_inv.restype = u32; L.orc_inv.argtypes = [u32, u32]
         L.orc_from_u32.restype = u32; L.orc_from_u32.argtypes = [u32, u32]
         L.orc_from_i32.restype = u32; L.orc_from_i32.argtypes = [C.c_int32, u32]
+        L.orc_div.restype = u32; L.orc_div.argtypes = [u32, u32, u32]
+        L.orc_rem.restype = u32; L.orc_rem.argtypes = [u32, u32, u32]
         L.orc_order.restype = u32; L.orc_order.argtypes = [u32, u32]
         L.orc_generator.restype = u32; L.orc_generator.argtypes = [u32]
         L.orc_lagrange_naive.restype = None; L.orc_lagrange_naive.argtypes = [vp, vp, sz, vp, u32]
@@ -123,6 +145,8 @@ def pow_(a, e, p=P): return lib().orc_pow(a, e, p)
 def inv(a, p=P): return lib().orc_inv(a, p)
 def from_u32(v, p=P): return lib().orc_from_u32(v, p)
 def from_i32(v, p=P): return lib().orc_from_i32(v, p)
+def div(a, b, p=P): return lib().orc_div(a, b, p)
+def rem(a, rhs, p=P): return lib().orc_rem(a, rhs, p)
 def order(a, p=P): return lib().orc_order(a, p)
 def generator(p=P): return lib().orc_generator(p)
 

@@ -56,6 +56,10 @@ uint32_t orc_from_i32(int32_t v, uint32_t p) {
     if (v < 0) return orc_neg((uint32_t)(-(int64_t)v) % p, p);
     return (uint32_t)v % p;
 }
+/* field.rs:165-177 Div: MontgomeryInt division = product with the inverse; a zero divisor panics there (returns 0 here). */
+uint32_t orc_div(uint32_t a, uint32_t b, uint32_t p) { return b % p ? orc_mul(a % p, orc_inv(b % p, p), p) : 0; }
+/* field.rs:89-94 Rem<u32>: convert(residue % rhs); rhs = 0 panics there (returns 0 here). */
+uint32_t orc_rem(uint32_t a, uint32_t rhs, uint32_t p) { return rhs ? (a % p) % rhs % p : 0; }
 /* field.rs:45-49 order(): brute force. */
 uint32_t orc_order(uint32_t a, uint32_t p) {
     uint32_t x = a % p;

@@ -47,6 +47,8 @@ uint32_t orc_pow(uint32_t a, uint32_t e, uint32_t p);
 uint32_t orc_inv(uint32_t a, uint32_t p);
 uint32_t orc_from_u32(uint32_t v, uint32_t p);  /* field.rs:20-24 */
 uint32_t orc_from_i32(int32_t v, uint32_t p);   /* field.rs:10-18 */
+uint32_t orc_div(uint32_t a, uint32_t b, uint32_t p);      /* field.rs:165-177 */
+uint32_t orc_rem(uint32_t a, uint32_t rhs, uint32_t p);    /* field.rs:89-94 */
 uint32_t orc_order(uint32_t a, uint32_t p);     /* field.rs:45-49 */
 uint32_t orc_generator(uint32_t p);             /* field.rs:52-86 */
 

@@ -104,6 +104,24 @@ def test_field_matches_oracle(zk, orc):
         assert f.pow(a, f.order(a)) == 1
     assert f.from_u32(3235878091) == 3235878091 - P        # field.rs:20-24: reduce raw u32 >= P
     assert f.add(P - 1, P - 1) == P - 2                    # P > 2^31: a + b overflows u32
+    # field.rs:165-177 Div, :10-18 From<i32>, :89-94 Rem<u32>
+    for _ in range(500):
+        a, b, m = rnd.randrange(P), rnd.randrange(1, P), rnd.randrange(1, 2**32)
+        q = f.div(a, b)
+        assert q == orc.div(a, b) == a * pow(b, P - 2, P) % P and f.mul(q, b) == a
+        assert f.rem(a, m) == orc.rem(a, m) == (a % m) % P
+        v = rnd.randrange(-2**31, 2**31)
+        assert f.from_i32(v) == orc.from_i32(v) == v % P
+    assert f.from_i32(-1) == P - 1 and f.from_i32(0) == 0 and f.from_i32(-2**31) == (-2**31) % P and f.from_i32(2**31 - 1) == 2**31 - 1
+    assert f.rem(P - 1, P - 1) == 0 and f.rem(5, 7) == 5 and f.div(0, 3) == 0 and f.div(7, 1) == 7
+    lib = zk.load()
+    assert lib.zk_field_div(1, 0) == 0 and b"division by zero" in lib.zk_last_error()      # the reference panics
+    assert lib.zk_field_div(1, P) == 0                                                       # a raw divisor = 0 (mod P)
+    assert lib.zk_field_rem(1, 0) == 0 and b"remainder by zero" in lib.zk_last_error()
+    with pytest.raises(ZeroDivisionError):
+        f.div(1, 0)
+    with pytest.raises(ZeroDivisionError):
+        f.rem(1, 0)
 
 
 def test_trace_fibsq(zk, orc):

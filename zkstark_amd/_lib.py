@@ -84,6 +84,9 @@ SYMBOLS = {
     "zk_field_inv": (_u32, [_u32]),
     "zk_field_pow": (_u32, [_u32, _u32]),
     "zk_field_from_u32": (_u32, [_u32]),
+    "zk_field_from_i32": (_u32, [C.c_int32]),
+    "zk_field_div": (_u32, [_u32, _u32]),
+    "zk_field_rem": (_u32, [_u32, _u32]),
     "zk_field_generator": (_u32, []),
     "zk_field_root_of_unity": (_u32, [_u32]),
     "zk_field_order": (_u32, [_u32]),

@@ -558,6 +558,21 @@ uint32_t zk_field_neg(uint32_t a) { return neg(a % P); }
 uint32_t zk_field_inv(uint32_t a) { return invmod(a % P); }
 uint32_t zk_field_pow(uint32_t a, uint32_t e) { return powmod(a, e); }
 uint32_t zk_field_from_u32(uint32_t v) { return v % P; }
+// field.rs:10-18 From<i32>: a negative value is the negation of |f| (i32::MIN: |f| = 2^31, what the release build's wrapping abs() gives)
+uint32_t zk_field_from_i32(int32_t v) {
+    if (v < 0) return neg(uint32_t(-int64_t(v)) % P);
+    return uint32_t(v) % P;
+}
+// field.rs:165-177 Div: a * b^-1.  The reference panics on a zero divisor (MontgomeryInt's inverse does not exist); here 0 and an error message.
+uint32_t zk_field_div(uint32_t a, uint32_t b) {
+    if (b % P == 0) { fail(ZK_ERR_INVALID, "zk_field_div: division by zero (field.rs:165-177 panics)"); return 0; }
+    return mulmod(a % P, invmod(b % P));
+}
+// field.rs:89-94 Rem<u32>: the RESIDUE reduced by an integer modulus, back in the field.  rhs = 0 panics there; here 0 and an error message.
+uint32_t zk_field_rem(uint32_t a, uint32_t rhs) {
+    if (rhs == 0) { fail(ZK_ERR_INVALID, "zk_field_rem: remainder by zero (field.rs:89-94 panics)"); return 0; }
+    return (a % P) % rhs;
+}
 // field.rs:52-86 Gf::generator(): the first x >= 2 with x^((P-1)/q) != 1 for every prime factor q of P - 1.  Searched as the
 // reference searches it (unique prime factors by trial division, then candidates in order), once; the kernels use the
 // constant GEN_W, which this search must -- and does -- return (5; pinned by tests/test_cabi.py).

@@ -42,6 +42,18 @@ class field:
     @staticmethod
     def from_u32(v): return _lib.load().zk_field_from_u32(v)
     @staticmethod
+    def from_i32(v): return _lib.load().zk_field_from_i32(v)   # field.rs:10-18
+    @staticmethod
+    def div(a, b):                                             # field.rs:165-177; a zero divisor panics there
+        if b % P == 0:
+            raise ZeroDivisionError("Gf division by zero (field.rs:165-177)")
+        return _lib.load().zk_field_div(a, b)
+    @staticmethod
+    def rem(a, rhs):                                           # field.rs:89-94
+        if rhs == 0:
+            raise ZeroDivisionError("Gf % 0 (field.rs:89-94)")
+        return _lib.load().zk_field_rem(a, rhs)
+    @staticmethod
     def generator(): return _lib.load().zk_field_generator()
     @staticmethod
     def root_of_unity(log_order): return _lib.load().zk_field_root_of_unity(log_order)
