@@ -135,7 +135,10 @@ int zk_trace_upload(zk_ctx *ctx, const uint32_t *trace, size_t count);
 /* lagrange (polynomial.rs:337) + solve over w*h^i (polynomial.rs:49, prover.rs:60-70):
  * layer 0 <- f(w h^i), i < N, natural order. */
 int zk_lde(zk_ctx *ctx);
-/* Merkle::new over a layer (merkle.rs:14-51; prover.rs:81, :176, :214); root = node 0. */
+/* Merkle::new over a layer (merkle.rs:14-51; prover.rs:81, :176, :214); root = node 0.  Returns once the root is known.  With
+ * a host hand-over (zk_ctx_set_host_levels) the device copy of the nodes this thread hashed (the top 8 levels) is ordered on
+ * the stream by the next call that reads trees or layers from the device (zk_merkle_node, zk_merkle_path, zk_layer_read,
+ * zk_ctx_sync, zk_ctx_stream), not by this one: a loop of commitments does not pay a copy launch per iteration. */
 int zk_merkle_commit(zk_ctx *ctx, uint32_t layer, uint8_t root_out[32]);
 /* Constraint quotients and their random combination (prover.rs:101-173):
  * layer 1 <- cp(w h^i).  alpha_raw are the raw u32 challenges (prover.rs:163-165). */
@@ -223,7 +226,9 @@ int zk_batch_set_hash(zk_batch *b, int hash_kind);
 /* on = 0: every tree level of the batch on the device (default: the host threads hash the top levels of each proof's
  * trees when the CPU has SHA extensions, as zk_ctx_set_host_levels).  Results are identical. */
 int zk_batch_set_host_levels(zk_batch *b, int on);
-/* Host threads that run the per-proof transcript steps and decommit hashing (default: hardware threads, at most 16). */
+/* Host threads that run the per-proof transcript steps and decommit hashing (default: hardware threads, at most 16).
+ * Like every zk_batch_set_* / trace call it is refused with ZK_ERR_STATE while a zk_batch_prove runs on the batch (one batch is
+ * used from one host thread at a time; the guard turns a misuse into an error instead of a freed pool under a running proof). */
 int zk_batch_set_threads(zk_batch *b, uint32_t threads);
 size_t zk_batch_device_bytes(const zk_batch *b);
 /* traces: [batch][n-1] canonical residues (prover.rs:32-39 per proof), uploaded and kept resident. */
@@ -340,11 +345,13 @@ typedef struct zk_shard_stats {
      * the time the exchange kernel waits for compute units beside the hashing); exposed_exchange_ms: the part of it the
      * hashing streams spent stalled (a plain exchange is exposed in full, a chunk only while its build waits for it);
      * tail_ms: host time of the replicated tail (all-gather of the first replicated layer, then zk_tail_run);
-     * selftest_ms: the known-pattern exchange run by zk_shard_create. */
+     * decommit_ms: host time from the query index to the last opening in the channel; selftest_ms: the known-pattern
+     * exchange run by zk_shard_create. */
     double exchange_ms;
     double exposed_exchange_ms;
     double tail_ms;
     double selftest_ms;
+    double decommit_ms;         /* host time of the decommitment (prover.rs:266-289), all queries, profiling on */
     uint32_t exchanges;         /* collectives timed (profiling on) */
     uint32_t selftest_ok;       /* 1: zk_shard_create's known-pattern all-to-all + all-gather arrived in the right places */
 } zk_shard_stats;
@@ -405,7 +412,9 @@ int zk_shard_set_queries(zk_shard *s, uint32_t n_queries);
  * enqueued: zk_shard_destroy of a failed prover then does not wait for its streams (they are leaked with a message).
  * zk_shard_inject_failure makes a rank fail that way on purpose (tests). */
 int zk_shard_inject_failure(zk_shard *s, int code);
-/* Known-pattern all-to-all + all-gather through the prover's transport (collective; see above). */
+/* Known-pattern all-to-all + all-gather through the prover's transport (collective; see above).  The pattern is written into
+ * the storage of layer 0 (f_eval) and the receive buffer: the layers resident from an earlier zk_shard_prove* / _lde_commit are
+ * INVALID afterwards (zk_shard_layer_read(0, ..) would return pattern words) until the next proof recomputes them. */
 int zk_shard_self_test(zk_shard *s);
 /* on != 0: time the exchanges of later proofs with HIP events (zk_shard_stats.exchange_ms ...); costs a few event
  * records per layer, so benchmarks switch it on for one untimed proof. */

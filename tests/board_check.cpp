@@ -46,9 +46,58 @@ static int run(int G, int rounds) {
     return 0;
 }
 
+// The blob area (the decommitment's contributions, shard.hip): every rank posts a blob of its own length per exchange and
+// reads every peer's blob of THAT exchange in place; a ring of two suffices because a rank posts exchange k + 1 only after
+// it has read all blobs of exchange k.
+static int run_blobs(int G, int rounds, size_t cap) {
+    char name[64];
+    snprintf(name, sizeof name, "/zkstark_amd_boardcheck_%d_b%d", (int)getpid(), G);
+    std::vector<RootBoard> boards(G);
+    if (!boards[0].open_or_create(name, 0, G, true, cap)) { fprintf(stderr, "create (blobs) failed\n"); return 1; }
+    for (int r = 1; r < G; ++r)
+        if (!boards[r].open_or_create(name, r, G, false, cap)) { fprintf(stderr, "open (blobs) failed\n"); return 1; }
+    {   // an opener that expects another blob capacity must be refused
+        RootBoard other;
+        if (other.open_or_create(name, 0, G, false, cap + 64)) { fprintf(stderr, "blob capacity mismatch accepted\n"); return 1; }
+    }
+    shm_unlink(name);
+    std::vector<int> bad(G, 0);
+    std::vector<std::thread> th;
+    auto word = [](int s, int r, size_t i) { return (uint32_t)s * 2246822519u + (uint32_t)r * 40503u + (uint32_t)i; };
+    for (int r = 0; r < G; ++r)
+        th.emplace_back([&, r] {
+            std::vector<uint32_t> mine(cap);
+            uint32_t roots[8], all[8 * 16];
+            for (int s = 1; s <= rounds; ++s) {
+                const size_t len = (size_t)((s * 7 + r * 13) % (int)cap);           // lengths differ per rank and exchange, 0 included
+                for (size_t i = 0; i < len; ++i) mine[i] = word(s, r, i);
+                if ((s + 3 * r) % 41 == 0) std::this_thread::sleep_for(std::chrono::microseconds(40));
+                boards[r].blob_post((uint64_t)s, mine.data(), len);
+                for (int q = 0; q < G; ++q) {
+                    const uint32_t* got = nullptr;
+                    if (boards[r].blob_wait((uint64_t)s, q, &got, 30.0) != RootBoard::kOk) { bad[r] = 1; return; }
+                    const size_t lq = (size_t)((s * 7 + q * 13) % (int)cap);
+                    for (size_t i = 0; i < lq; ++i)
+                        if (got[i] != word(s, q, i)) { bad[r] = 2; return; }
+                }
+                if (s % 5 == 0) {                                                   // root exchanges interleave with blob exchanges in a proof
+                    for (int i = 0; i < 8; ++i) roots[i] = word(s, r, 1000 + i);
+                    if (boards[r].exchange((uint64_t)(s / 5), roots, all, 30.0) != RootBoard::kOk) { bad[r] = 3; return; }
+                }
+            }
+        });
+    for (auto& t : th) t.join();
+    for (auto& b : boards) b.close();
+    for (int r = 0; r < G; ++r)
+        if (bad[r]) { fprintf(stderr, "blobs, G = %d: rank %d failed (%d)\n", G, r, bad[r]); return 1; }
+    return 0;
+}
+
 int main() {
     for (int G : {1, 2, 4, 8})
         if (run(G, G == 8 ? 1500 : 4000)) return 1;
+    for (int G : {1, 2, 8})
+        if (run_blobs(G, G == 8 ? 600 : 2000, 96)) return 1;
     // timeout: a rank that never posts
     RootBoard lone;
     char name[64];

@@ -23,6 +23,83 @@ def test_bench_gpus_n_spawns_ranks_and_needs_n_gpus():
     assert out.stdout.strip() == ""                                       # no JSON line for an unmeasured run
 
 
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("zk_bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_sigterm_ends_supervisors_and_workers():
+    """An outer `timeout` (SIGTERM to the launcher) must not orphan the workers that hold the GPU: the launcher forwards the
+    signal, every supervisor ends its worker, and the rendezvous files of the run are removed."""
+    import glob
+    import signal
+    import time
+    import psutil
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ZK_BENCH_TEST_WORKER_SLEEP"] = "60"
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        deadline = time.time() + 30
+        kids = []
+        while time.time() < deadline:                      # launcher -> 2 supervisors -> 2 workers
+            kids = psutil.Process(p.pid).children(recursive=True)
+            if len(kids) >= 4:
+                break
+            time.sleep(0.1)
+        assert len(kids) >= 4, [k.cmdline() for k in kids]
+        tag_files = lambda: [f for f in glob.glob("/tmp/zkbench_*") if f"_{p.pid}_" in f]
+        assert tag_files()                                 # generation / status files of this run exist while it runs
+        p.send_signal(signal.SIGTERM)
+        out, err = p.communicate(timeout=40)
+        assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-2000:])
+        gone, alive = psutil.wait_procs(kids, timeout=15)
+        assert not alive, [a.cmdline() for a in alive]
+        assert out.strip() == ""
+        assert tag_files() == []
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+def test_bench_worker_generations_agree():
+    """The ranks' supervisors agree on the worker generation through one shared file: a rank whose worker died once more
+    than its peers' does not wait alone in a rendezvous nobody else opens."""
+    import threading
+    b = _load_bench()
+    tag = f"unittest_{os.getpid()}"
+    try:
+        # rank 0 is at its 3rd worker, rank 1 at its 1st: both land in generation 2
+        g0 = b._bump_generation(tag, 2, 2)
+        g1 = b._bump_generation(tag, 0, 2)
+        assert g0 == g1 == 2 and b._current_generation(tag) == 2
+        res = {}
+        th = [threading.Thread(target=lambda r=r: res.__setitem__(r, b.join_generation(tag, 2, r, 2, 10.0))) for r in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert res == {0: "ok", 1: "ok"}
+        # a worker waiting in generation 2 while the run moves on to 3 leaves at once; one whose peer never comes times out
+        stale = {}
+        t = threading.Thread(target=lambda: stale.__setitem__("r", b.join_generation(tag, 3, 0, 2, 10.0)))
+        assert b._bump_generation(tag, 3, 2) == 3
+        t.start()
+        assert b._bump_generation(tag, 4, 2) == 4
+        t.join()
+        assert stale["r"] == "stale"
+        assert b.join_generation(tag, 4, 0, 2, 0.3) == "timeout"
+        # opening a generation removes what a killed run left under the same names
+        store, joins = b._gen_paths(tag, 7, 2)
+        for f in [store] + joins:
+            open(f, "w").close()
+        assert b._bump_generation(tag, 7, 2) == 7 and not any(os.path.exists(f) for f in [store] + joins)
+    finally:
+        import glob
+        for f in glob.glob(f"/tmp/zkbench_*{tag}*"):
+            os.unlink(f)
+
+
 @pytest.mark.gpu
 def test_bench_n2_rehearsal_on_one_gpu():
     """The N > 1 leg end to end (rank spawn, unique-id broadcast, native sharded prover, max over ranks, one JSON
@@ -39,6 +116,13 @@ def test_bench_n2_rehearsal_on_one_gpu():
     assert rec["parity_checked"] is True and rec["shard"]["ranks_agree"] is True
     assert rec["shard"]["sharded_layers"] >= 1 and rec["lde_commit_sharded"]["root_stable"] is True
     assert rec["config"]["domain"] == 1 << 21 and rec["value"] == pytest.approx((1 << 21) / (rec["ms_per_step"] * 1e-3), rel=1e-6)
+    # the strong-scaling leg at the single-GPU domain (here 2^20) rides in the same line, compared with the single-GPU prover
+    st = rec["strong_2e20"]
+    assert "2^20" in st["workload"] and st["parity"]["equal"] is True and st["ranks_agree"] is True and st["first_proof_verifies"] is True
+    assert st["value"] == pytest.approx((1 << 20) / (st["ms"] * 1e-3), rel=1e-6) and st["single_gpu_ms"] > 0
+    assert st["shard"]["plan"]["sharded_layers"] >= 1 and len(st["shard"]["per_rank"]) == 2
+    assert all(k in st["shard"]["per_rank"][1] for k in ("exchange_ms", "exposed_exchange_ms", "tail_ms", "decommit_ms"))
+    assert "legs_skipped" not in rec
 
 
 @pytest.mark.gpu
@@ -70,7 +154,7 @@ def test_bench_sharded_transports_one_rank(env_extra, want_transport):
         assert lad["worker"] == 2 and lad["rung"] == 2 and "WATCHDOG" in out.stderr and lad["seconds_since_supervisor_start"] < 120
     else:
         assert lad["worker"] == 0
-    for k in ("exchange_ms", "exposed_exchange_ms", "tail_ms", "per_rank", "plan"):
+    for k in ("exchange_ms", "exposed_exchange_ms", "tail_ms", "decommit_ms", "per_rank", "plan"):
         assert k in rec["shard"], k
     assert rec["shard"]["per_rank"][0]["rank"] == 0 and rec["shard"]["per_rank"][0]["exchanges"] > 0
     assert rec["shard"]["native_rccl"] == (1 if want_transport == "native" else 0)

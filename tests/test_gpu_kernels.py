@@ -361,6 +361,41 @@ def test_merkle_index_and_path_api(zk, orc):
             ctx.merkle_node(0, 2047)
 
 
+def test_merkle_commit_pending_tree_top(zk, orc):
+    """zk_merkle_commit returns with the root and leaves the device copy of the host-built tree top pending: a second commitment
+    of the SAME tree supersedes it, a commitment of ANOTHER tree or a proof must not lose it, and every reader of the device
+    arrays sees whole trees (merkle.rs:14-79)."""
+    if zk.host_hash_mode() == "portable":
+        pytest.skip("no host hand-over on this CPU: nothing is ever pending")
+    a = zk.trace_fibsq((1 << 12) - 1)
+    with zk.Context(12, 3) as ctx:
+        ctx.trace_upload(a)
+        ctx.lde()
+        f = ctx.layer_read(0)
+        r0 = ctx.merkle_commit(0)                              # top of tree 0 pending
+        g = (f.astype(np.uint64) * 3 % P).astype(np.uint32)
+        ctx.layer_write(1, g)
+        r1 = ctx.merkle_commit(1)                              # another tree: tree 0's top must reach the device first
+        n0, n1 = orc.merkle_build(f), orc.merkle_build(g)
+        assert r0 == bytes(n0[0]) and r1 == bytes(n1[0])
+        for idx in (0, 1, 2, 200, 254, 255, 511, 4000):         # top 8 levels (host-built) and below
+            assert ctx.merkle_node(0, idx) == bytes(n0[idx]) and ctx.merkle_node(1, idx) == bytes(n1[idx])
+        h = (f.astype(np.uint64) * 5 % P).astype(np.uint32)
+        ctx.layer_write(1, h)
+        r1b = ctx.merkle_commit(1)                             # the same tree again, twice: the older pending top is dropped
+        r1c = ctx.merkle_commit(1)
+        n2 = orc.merkle_build(h)
+        assert r1b == r1c == bytes(n2[0])
+        assert ctx.merkle_path(1, 12345) == [bytes(x) for x in orc.merkle_trace(n2, 12345)]
+        assert ctx.merkle_path(0, 77) == [bytes(x) for x in orc.merkle_trace(n0, 77)]
+        r0b = ctx.merkle_commit(0)                             # pending, then a whole proof on the same context
+        assert r0b == r0
+        want = orc.prove(12, 3, want_vectors=False)
+        p = ctx.prove()
+        assert p.data == want.proof and p.state == want.state
+        assert ctx.merkle_node(0, 3) == bytes(n0[3])           # the proof rebuilt tree 0 from the same trace
+
+
 @pytest.mark.parametrize("q", [2, 7, 64])
 def test_prover_multi_query(zk, orc, q):
     """q decommitment queries: proof bytes equal to the oracle's, strict verifier accepts.

@@ -49,7 +49,7 @@ class ShardOptions(C.Structure):
 class ShardStats(C.Structure):
     _fields_ = [("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
                 ("rccl_nranks", C.c_uint32), ("communicators", C.c_uint32), ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double),
-                ("exchange_ms", C.c_double), ("exposed_exchange_ms", C.c_double), ("tail_ms", C.c_double), ("selftest_ms", C.c_double),
+                ("exchange_ms", C.c_double), ("exposed_exchange_ms", C.c_double), ("tail_ms", C.c_double), ("selftest_ms", C.c_double), ("decommit_ms", C.c_double),
                 ("exchanges", C.c_uint32), ("selftest_ok", C.c_uint32)]
 
 

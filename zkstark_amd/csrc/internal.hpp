@@ -122,6 +122,9 @@ int dom_fold(const zk_dom* d, const uint32_t* d_in, uint32_t* d_out, uint32_t lo
 // timeout_s: how long to wait for the flag (the sharded prover passes its own bound: the launch may sit behind an exchange)
 int wait_flag(const uint32_t* flag, uint32_t want, hipStream_t stream, int (*poll)(void*) = nullptr, void* poll_user = nullptr, double timeout_s = 30.0);
 double now_us();
+// zk_tail_open in two steps (zkstark.hip): begin enqueues at most one launch on the tail's stream, end waits and copies out
+int tail_open_begin(zk_ctx* tail, size_t x);
+int tail_open_end(zk_ctx* tail, uint32_t* vals_out, uint8_t* paths_out);
 // merkle.rs:54-71: node indices of the authentication path of `leaf` in a tree of m leaves
 void path_nodes(size_t m, size_t leaf, std::vector<size_t>& out);
 

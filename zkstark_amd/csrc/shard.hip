@@ -141,6 +141,14 @@ struct zk_shard {
     uint32_t *d_gout = nullptr, *d_gall = nullptr, *h_gall = nullptr;
     size_t gather_slots = 0, gather_words = 0;
     uint32_t* h_small = nullptr;                       // pinned scratch (subtree roots, flags)
+    // one-launch decommitment (fetch_kernel): work list and results in host-mapped memory, flag behind the results
+    uint64_t *h_fitems = nullptr, *dm_fitems = nullptr;
+    uint32_t *h_fout = nullptr, *dm_fout = nullptr;
+    uint32_t *h_fmail = nullptr, *dm_fmail = nullptr, *d_fcounter = nullptr;
+    uint32_t fetch_seq = 0;
+    uint64_t blob_seq = 0;                             // decommitment contributions through the shared page (board.blob_*)
+    std::vector<uint32_t> blob_buf;
+    double decommit_ms_acc = 0;
     // root board
     RootBoard board;
     bool have_board = false;                           // the shared page is mapped: abort words work
@@ -273,7 +281,8 @@ void reset_timing(zk_shard* s) {
     for (auto& t : s->timed) { s->ev_pool.push_back(t.a); s->ev_pool.push_back(t.b); }
     s->timed.clear();
     s->tail_ms_acc = 0;
-    s->stats.exchange_ms = s->stats.exposed_exchange_ms = s->stats.tail_ms = 0;
+    s->decommit_ms_acc = 0;
+    s->stats.exchange_ms = s->stats.exposed_exchange_ms = s->stats.tail_ms = s->stats.decommit_ms = 0;
     s->stats.exchanges = 0;
 }
 void collect_timing(zk_shard* s) {
@@ -288,6 +297,7 @@ void collect_timing(zk_shard* s) {
     }
     s->timed.clear();
     s->stats.tail_ms = s->tail_ms_acc;
+    s->stats.decommit_ms = s->decommit_ms_acc;
 }
 int all_to_all(zk_shard* s, const uint32_t* const* send, uint32_t* const* recv, size_t words, hipStream_t st) {
     int rc = before_collective(s, st);
@@ -455,25 +465,34 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
 
 int do_lde(zk_shard* s) { return zk_dev_lde(s->dom_loc, s->d_trace, s->d_coef, layer_ptr(s, 0), s->stream); }
 
-// prover.rs:266-289.  Every rank gathers the slots it owns (the same slot list everywhere), one all-gather merges
-// them, every rank assembles the same bytes.
-int decommit(zk_shard* s, Channel& ch, size_t x) {
-    const int G = s->G, me = s->rank;
+// prover.rs:266-289.  The slot list (4 + 2 rho0 openings: a value and the nodes of its path inside the owner's subtree) is
+// the same on every rank; every rank fetches the slots it owns and the contributions are merged, so that every rank
+// assembles the same bytes.  Two forms:
+//   * ranks on one node (the shared page is mapped), or no collectives at all: ONE launch (fetch_kernel) reads this rank's
+//     work list from host-mapped memory, writes its results there and raises a flag -- no copy command, no stream
+//     synchronisation, as in the single-GPU prover (zkstark.hip: open_launch) --, the contributions travel through the page
+//     (board.blob_post / blob_wait: one store and G polled loads), and the openings of the replicated tail are fetched by a
+//     launch of their own that is in flight at the same time (tail_open_begin / _end);
+//   * otherwise (another node, no_root_board, plain_collectives): two gathers, one all-gather, a device-to-host copy.
+struct DecommitItem { int owner; uint64_t off; };
+struct DecommitOpen { size_t nloc; uint32_t lid; size_t block; };
+struct DecommitPlan {
+    std::vector<DecommitItem> vit, dit;
+    std::vector<DecommitOpen> opens;
+};
+void decommit_plan(zk_shard* s, size_t x, DecommitPlan& pl) {
     const size_t B = s->B, N = s->N;
     const uint32_t L = s->L, rho0 = s->n_sharded;
-    struct Item { int owner; uint64_t off; };
-    std::vector<Item> vit, dit;
-    struct Open { size_t nloc; uint32_t lid; size_t block; };
-    std::vector<Open> opens;
+    const int G = s->G;
     std::vector<size_t> nodes;
     auto add_opening = [&](uint32_t lid, size_t leaf, uint32_t m_log) {
         const size_t blk = ((size_t)1 << m_log) >> s->lg;
         const size_t p = leaf / blk, lf = leaf % blk;
-        vit.push_back({(int)(leaf % (size_t)G), (uint64_t)(s->layer_off[lid] + leaf / (size_t)G)});
+        pl.vit.push_back({(int)(leaf % (size_t)G), (uint64_t)(s->layer_off[lid] + leaf / (size_t)G)});
         nodes.clear();
         path_nodes(blk, lf, nodes);
-        for (size_t nd : nodes) dit.push_back({(int)p, (uint64_t)s->tree_off[lid] + (uint64_t)nd * 8});
-        opens.push_back({nodes.size(), lid, p});
+        for (size_t nd : nodes) pl.dit.push_back({(int)p, (uint64_t)s->tree_off[lid] + (uint64_t)nd * 8});
+        pl.opens.push_back({nodes.size(), lid, p});
     };
     add_opening(0, x, L); add_opening(0, x + B, L); add_opening(0, x + 2 * B, L); add_opening(1, x, L);   // prover.rs:266-277
     for (uint32_t i = 0; i < rho0; ++i) {                                                                   // prover.rs:280-289
@@ -481,37 +500,19 @@ int decommit(zk_shard* s, Channel& ch, size_t x) {
         add_opening(1 + i, xi, L - i);
         add_opening(1 + i, nx, L - i);
     }
-    const size_t nv = vit.size(), nd = dit.size(), row = nv + 8 * nd;
-    if (nv + nd > s->gather_slots || row > s->gather_words) return fail(ZK_ERR_STATE, "zk_shard: gather capacity exceeded");
-    for (size_t i = 0; i < nv; ++i) s->h_goff[i] = vit[i].owner == me ? vit[i].off : 0;
-    for (size_t i = 0; i < nd; ++i) s->h_goff[nv + i] = dit[i].owner == me ? dit[i].off : 0;
-    int rc;
-    HIPCHK(hipMemcpyAsync(s->d_goff, s->h_goff, (nv + nd) * 8, hipMemcpyHostToDevice, s->stream));
-    if ((rc = zk_dev_gather(s->d_layers, s->d_goff, (uint32_t)nv, 1, s->d_gout, s->stream))) return rc;
-    if ((rc = zk_dev_gather(s->d_trees, s->d_goff + nv, (uint32_t)nd, 8, s->d_gout + nv, s->stream))) return rc;
-    if (collectives(s)) {
-        if ((rc = all_gather(s, s->d_gout, s->d_gall, row, s->stream))) return rc;
-        HIPCHK(hipMemcpyAsync(s->h_gall, s->d_gall, row * 4 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
-    } else {
-        HIPCHK(hipMemcpyAsync(s->h_gall, s->d_gout, row * 4, hipMemcpyDeviceToHost, s->stream));
-    }
-    // the tail layers' openings come from the replicated tail (every rank has them)
-    std::vector<uint32_t> tvals(2 * (size_t)s->tail_rounds + 1);
-    size_t tdig = 0;
-    for (uint32_t j = 0; j < s->tail_rounds; ++j) tdig += 2 * (size_t)(L - rho0 - j);
-    std::vector<uint8_t> tpaths(32 * tdig + 1);
-    if ((rc = zk_tail_open(s->tail, x, tvals.data(), tpaths.data()))) return rc;
-    if ((rc = sync_peers(s, s->stream, "the all-gather of the decommitment"))) return rc;
-    auto val_of = [&](size_t i) { return s->h_gall[(size_t)vit[i].owner * row * (collectives(s) ? 1 : 0) + i]; };
+}
+// The transcript part, shared by both forms: val_of(i) = value of opening i, dig_of(j) = the 8 state words of path node j
+template <typename ValOf, typename DigOf>
+void decommit_commit(zk_shard* s, Channel& ch, const DecommitPlan& pl, ValOf val_of, DigOf dig_of, const uint32_t* tvals, const uint8_t* tpaths) {
+    const uint32_t L = s->L, rho0 = s->n_sharded;
+    const int G = s->G;
     std::vector<uint8_t> path;
+    std::vector<size_t> nodes;
     size_t dpos = 0;
-    auto path_of = [&](size_t k) -> const uint8_t* {          // opening k: local digests from their owner's row, then the top path
-        const Open& o = opens[k];
+    auto path_of = [&](size_t k) -> const uint8_t* {          // opening k: the digests inside its owner's subtree, then the top path
+        const DecommitOpen& o = pl.opens[k];
         path.resize(32 * (o.nloc + s->lg));
-        for (size_t i = 0; i < o.nloc; ++i) {
-            const size_t r = collectives(s) ? (size_t)dit[dpos + i].owner : 0;
-            digest_words_to_bytes(s->h_gall + r * row + nv + 8 * (dpos + i), path.data() + 32 * i);
-        }
+        for (size_t i = 0; i < o.nloc; ++i) digest_words_to_bytes(dig_of(dpos + i), path.data() + 32 * i);
         dpos += o.nloc;
         nodes.clear();
         if (G > 1) path_nodes((size_t)G, o.block, nodes);
@@ -524,18 +525,90 @@ int decommit(zk_shard* s, Channel& ch, size_t x) {
     }
     std::vector<uint8_t> p0;
     for (uint32_t i = 0; i < rho0; ++i) {                     // prover.rs:288
-        const size_t pl = L - i;
+        const size_t plen = L - i;
         const uint8_t* a = path_of(4 + 2 * i);
-        p0.assign(a, a + 32 * pl);
+        p0.assign(a, a + 32 * plen);
         const uint8_t* b = path_of(5 + 2 * i);
-        ch.commit_pair_paths(val_of(4 + 2 * i), val_of(5 + 2 * i), p0.data(), b, pl);
+        ch.commit_pair_paths(val_of(4 + 2 * i), val_of(5 + 2 * i), p0.data(), b, plen);
     }
     size_t tp = 0;
-    for (uint32_t j = 0; j < s->tail_rounds; ++j) {           // the replicated layers, from zk_tail_open
-        const size_t pl = L - rho0 - j;
-        ch.commit_pair_paths(tvals[2 * j], tvals[2 * j + 1], tpaths.data() + 32 * tp, tpaths.data() + 32 * (tp + pl), pl);
-        tp += 2 * pl;
+    for (uint32_t j = 0; j < s->tail_rounds; ++j) {           // the replicated layers, from the tail's own openings
+        const size_t plen = L - rho0 - j;
+        ch.commit_pair_paths(tvals[2 * j], tvals[2 * j + 1], tpaths + 32 * tp, tpaths + 32 * (tp + plen), plen);
+        tp += 2 * plen;
     }
+}
+
+int decommit(zk_shard* s, Channel& ch, size_t x) {
+    const int G = s->G, me = s->rank;
+    const uint32_t L = s->L, rho0 = s->n_sharded;
+    const double t_begin = now_us();
+    DecommitPlan pl;
+    decommit_plan(s, x, pl);
+    const size_t nv = pl.vit.size(), nd = pl.dit.size(), row = nv + 8 * nd;
+    if (nv + nd > s->gather_slots || row > s->gather_words) return fail(ZK_ERR_STATE, "zk_shard: gather capacity exceeded");
+    std::vector<uint32_t> tvals(2 * (size_t)s->tail_rounds + 1);
+    size_t tdig = 0;
+    for (uint32_t j = 0; j < s->tail_rounds; ++j) tdig += 2 * (size_t)(L - rho0 - j);
+    std::vector<uint8_t> tpaths(32 * tdig + 1);
+    int rc;
+    if (!collectives(s) || s->use_board) {
+        // my slots, compact: values first, then digests (the order of the plan)
+        size_t mv = 0, mdg = 0;
+        for (size_t i = 0; i < nv; ++i) if (pl.vit[i].owner == me || !collectives(s)) s->h_fitems[mv++] = pl.vit[i].off;
+        for (size_t i = 0; i < nd; ++i) if (pl.dit[i].owner == me || !collectives(s)) s->h_fitems[mv + mdg++] = pl.dit[i].off;
+        const bool fetch = mv + mdg != 0;
+        if (fetch) HIPCHK(launch_fetch(s->d_layers, s->d_trees, s->dm_fitems, (uint32_t)mv, (uint32_t)mdg, s->dm_fout, s->dm_fmail, ++s->fetch_seq,
+                                       s->d_fcounter, s->stream, nullptr));
+        if ((rc = tail_open_begin(s->tail, x))) return rc;                       // in flight beside it, on the tail's stream
+        if (fetch && (rc = wait_flag(s->h_fmail, s->fetch_seq, s->stream, s->have_board ? poll_peer_abort : nullptr, s, s->timeout_s))) return rc;
+        // fetch_kernel's result layout: the mdg digests (8 words each), then the mv values
+        const uint32_t* mine = s->h_fout;
+        std::vector<const uint32_t*> from(G, nullptr);
+        std::vector<size_t> cnt_v(G, 0), cnt_d(G, 0);
+        if (collectives(s)) {
+            for (size_t i = 0; i < nv; ++i) cnt_v[pl.vit[i].owner] += 1;
+            for (size_t i = 0; i < nd; ++i) cnt_d[pl.dit[i].owner] += 1;
+            s->board.blob_post(++s->blob_seq, mine, 8 * mdg + mv);
+            for (int q = 0; q < G; ++q) {
+                if (q == me) { from[q] = mine; continue; }
+                const RootBoard::Status bs = s->board.blob_wait(s->blob_seq, q, &from[q], s->timeout_s);
+                if (bs == RootBoard::kPeerAborted)
+                    return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d (seen in the decommitment exchange #%llu)", me, G,
+                                s->board.bad_peer, -(int)s->board.bad_code, (unsigned long long)s->blob_seq);
+                if (bs != RootBoard::kOk)
+                    return fail(ZK_ERR_HIP, "rank %d of %d: rank %d did not post its openings (decommitment exchange #%llu timed out after %.0f s)", me, G,
+                                s->board.bad_peer, (unsigned long long)s->blob_seq, s->timeout_s);
+            }
+        } else {
+            from[0] = mine; cnt_v[0] = nv; cnt_d[0] = nd;
+        }
+        // position of slot i inside its owner's compact contribution
+        std::vector<size_t> vpos(nv), dpos_in(nd), seen_v(G, 0), seen_d(G, 0);
+        for (size_t i = 0; i < nv; ++i) { const int o = collectives(s) ? pl.vit[i].owner : 0; vpos[i] = seen_v[o]++; }
+        for (size_t i = 0; i < nd; ++i) { const int o = collectives(s) ? pl.dit[i].owner : 0; dpos_in[i] = seen_d[o]++; }
+        if ((rc = tail_open_end(s->tail, tvals.data(), tpaths.data()))) return rc;
+        auto val_of = [&](size_t i) { const int o = collectives(s) ? pl.vit[i].owner : 0; return from[o][8 * cnt_d[o] + vpos[i]]; };
+        auto dig_of = [&](size_t j) { const int o = collectives(s) ? pl.dit[j].owner : 0; return from[o] + 8 * dpos_in[j]; };
+        decommit_commit(s, ch, pl, val_of, dig_of, tvals.data(), tpaths.data());
+        s->decommit_ms_acc += (now_us() - t_begin) * 1e-3;
+        return ZK_OK;
+    }
+    // collectives without the shared page: every rank gathers the slots it owns into a full row, one all-gather merges the rows
+    for (size_t i = 0; i < nv; ++i) s->h_goff[i] = pl.vit[i].owner == me ? pl.vit[i].off : 0;
+    for (size_t i = 0; i < nd; ++i) s->h_goff[nv + i] = pl.dit[i].owner == me ? pl.dit[i].off : 0;
+    HIPCHK(hipMemcpyAsync(s->d_goff, s->h_goff, (nv + nd) * 8, hipMemcpyHostToDevice, s->stream));
+    if ((rc = zk_dev_gather(s->d_layers, s->d_goff, (uint32_t)nv, 1, s->d_gout, s->stream))) return rc;
+    if ((rc = zk_dev_gather(s->d_trees, s->d_goff + nv, (uint32_t)nd, 8, s->d_gout + nv, s->stream))) return rc;
+    if ((rc = all_gather(s, s->d_gout, s->d_gall, row, s->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(s->h_gall, s->d_gall, row * 4 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
+    if ((rc = tail_open_begin(s->tail, x))) return rc;        // the tail layers' openings: every rank has them
+    if ((rc = sync_peers(s, s->stream, "the all-gather of the decommitment"))) return rc;
+    if ((rc = tail_open_end(s->tail, tvals.data(), tpaths.data()))) return rc;
+    auto val_of = [&](size_t i) { return s->h_gall[(size_t)pl.vit[i].owner * row + i]; };
+    auto dig_of = [&](size_t j) { return s->h_gall + (size_t)pl.dit[j].owner * row + nv + 8 * j; };
+    decommit_commit(s, ch, pl, val_of, dig_of, tvals.data(), tpaths.data());
+    s->decommit_ms_acc += (now_us() - t_begin) * 1e-3;
     return ZK_OK;
 }
 
@@ -782,7 +855,8 @@ int zk_shard_destroy(zk_shard* s) {
     for (void* p : {(void*)s->d_trace, (void*)s->d_coef, (void*)s->d_layers, (void*)s->d_trees, (void*)s->d_recv, (void*)s->d_gbuf,
                     (void*)s->d_repl, (void*)s->d_small, (void*)s->d_goff, (void*)s->d_gout, (void*)s->d_gall})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)s->h_goff, (void*)s->h_gall, (void*)s->h_small})
+    if (s->d_fcounter) (void)hipFree(s->d_fcounter);
+    for (void* p : {(void*)s->h_goff, (void*)s->h_gall, (void*)s->h_small, (void*)s->h_fitems, (void*)s->h_fout, (void*)s->h_fmail})
         if (p) (void)hipHostFree(p);
     if (s->ev_layer) (void)hipEventDestroy(s->ev_layer);
     if (s->ev_coll) (void)hipEventDestroy(s->ev_coll);
@@ -938,6 +1012,15 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         return bail(rc);
     HIPCHK_S(hipHostMalloc((void**)&s->h_goff, s->gather_slots * 8));
     HIPCHK_S(hipHostMalloc((void**)&s->h_gall, s->gather_words * 4 * (size_t)world));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_fitems, s->gather_slots * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_fout, s->gather_words * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_fmail, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(s->h_fmail, 0, 64);
+    HIPCHK_S(hipHostGetDevicePointer((void**)&s->dm_fitems, s->h_fitems, 0));
+    HIPCHK_S(hipHostGetDevicePointer((void**)&s->dm_fout, s->h_fout, 0));
+    HIPCHK_S(hipHostGetDevicePointer((void**)&s->dm_fmail, s->h_fmail, 0));
+    if ((rc = dalloc(s, &s->d_fcounter, 64))) return bail(rc);
+    HIPCHK_S(hipMemsetAsync(s->d_fcounter, 0, 64, s->stream));
     s->tops.resize(ns + 1);
     s->device_bytes += (double)zk_ctx_device_bytes(s->tail);
     // A shared-memory page when every rank can map the object (one node): the abort words always, and the subtree roots
@@ -948,9 +1031,9 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         char name[64];
         snprintf(name, sizeof name, "/zkstark_amd_%02x%02x%02x%02x%02x%02x%02x%02x", dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], dg[6], dg[7]);
         bool ok = true, all = false;
-        if (rank == 0) ok = s->board.open_or_create(name, rank, world, true);
+        if (rank == 0) ok = s->board.open_or_create(name, rank, world, true, s->gather_words);
         if ((rc = agree(s, ok, &all))) return bail(rc);        // the object exists (or rank 0 failed) before anybody opens it
-        if (all && rank != 0) ok = s->board.open_or_create(name, rank, world, false);
+        if (all && rank != 0) ok = s->board.open_or_create(name, rank, world, false, s->gather_words);
         bool mapped = false;
         if ((rc = agree(s, all && ok, &mapped))) return bail(rc);   // everybody has mapped it: the name can go
         if (rank == 0) shm_unlink(name);

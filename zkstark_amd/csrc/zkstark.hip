@@ -64,6 +64,13 @@ struct zk_ctx {
     std::vector<uint32_t> fetch_vdev;
     std::vector<uint64_t> fetch_ditems;
     std::vector<uint8_t> commit_buf;
+    // zk_merkle_commit leaves the device copy of the host-built tree top PENDING (the segments stay in the staging buffer):
+    // it is ordered on the stream by the first call that reads trees or layers from the device, dropped by a later
+    // commitment of the same tree or a proof (both rebuild those nodes), flushed before any other reuse of the staging buffer
+    bool pending_top = false;
+    uint32_t pending_tree = 0;
+    size_t open_nv = 0, open_ndg = 0, open_vi = 0;   // the decommitment being assembled (open_begin ..)
+    bool open_pending = false;
     uint32_t* h_small = nullptr;        // pinned: root words + last layer
     uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: layout in kernels.hpp (MailArgs)
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
@@ -307,8 +314,12 @@ void begin_proof(zk_ctx* c) {
 int flush_host_parts(zk_ctx* c) {
     HIPCHK(launch_scatter(c->d_stage, c->d_segs, c->n_segs, c->seg_words, c->d_trees, c->d_layers, c->stream, prof_of(c)));
     c->n_segs = 0;
+    c->pending_top = false;
     return ZK_OK;
 }
+// Before anything reads trees / layers from the device, or the stream is handed out: the tree top a stand-alone commitment
+// left pending is copied now.
+int settle_pending(zk_ctx* c) { return c->pending_top ? flush_host_parts(c) : (int)ZK_OK; }
 // B evaluations of a degree-0 polynomial (prover.rs:238, :251) -> the free term (prover.rs:254)
 int last_layer_value(zk_ctx* c, uint32_t* out) {
     const uint32_t* v;
@@ -404,6 +415,45 @@ int check_degree(zk_ctx* c, uint32_t layer, uint32_t want_deg, const char* cite)
     return ZK_OK;
 }
 
+// ---- openings (prover.rs:266-289): where a value or a path node comes from -----------------------------------------
+// Values and path nodes this thread built itself during the proof (tree tops, the small FRI layers and their trees) are
+// still in the staging buffer and are read from there; everything else comes back through ONE launch (fetch_kernel) that
+// takes its work list from host-mapped memory, writes its results there and raises the mailbox flag behind them: no copy
+// commands, no stream synchronisation.  open_begin .. open_val / open_path .. open_launch .. open_wait; afterwards
+// c->fetch_vals[i] / c->fetch_nodes[j] point at value i / path node j in the order they were asked for.
+void open_begin(zk_ctx* c, size_t nvals) {
+    c->fetch_vals.assign(nvals, nullptr); c->fetch_vdev.assign(nvals, 0); c->fetch_nodes.clear(); c->fetch_ditems.clear();
+    c->open_nv = c->open_ndg = c->open_vi = 0;
+}
+void open_val(zk_ctx* c, uint32_t layer, size_t x) {
+    if (c->host_vals[layer]) c->fetch_vals[c->open_vi++] = c->host_vals[layer] + x;
+    else { c->fetch_vdev[c->open_vi++] = (uint32_t)c->open_nv; c->h_gather_off[c->open_nv++] = (uint64_t)c->layer_off[layer] + x; }
+}
+void open_path(zk_ctx* c, uint32_t tree, size_t m, size_t leaf) {          // merkle.rs:54-71: the sibling at every depth
+    for (size_t i = leaf + m - 1; i != 0; i = (i - 1) >> 1) {
+        const size_t nd = (i & 1) ? i + 1 : i - 1;
+        if (nd < c->host_node_cnt[tree]) c->fetch_nodes.push_back(c->host_nodes[tree] + 8 * nd);
+        else { c->fetch_nodes.push_back(c->h_gather_out + 8 * c->open_ndg); ++c->open_ndg; c->fetch_ditems.push_back((uint64_t)c->tree_off[tree] + (uint64_t)nd * 8); }
+    }
+}
+int open_launch(zk_ctx* c) {
+    const size_t nv = c->open_nv, ndg = c->open_ndg;
+    if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
+    if (ndg) memcpy(c->h_gather_off + nv, c->fetch_ditems.data(), ndg * 8);
+    for (size_t i = 0; i < c->fetch_vals.size(); ++i)
+        if (!c->fetch_vals[i]) c->fetch_vals[i] = c->h_gather_out + 8 * ndg + c->fetch_vdev[i];
+    c->open_pending = nv + ndg != 0;
+    if (c->open_pending)
+        HIPCHK(launch_fetch(c->d_layers, c->d_trees, c->dm_gather_off, (uint32_t)nv, (uint32_t)ndg, c->dm_gather_out, c->d_mailbox,
+                            ++c->mail_seq, c->d_counter, c->stream, prof_of(c)));
+    return ZK_OK;
+}
+int open_wait(zk_ctx* c) {
+    if (!c->open_pending) return ZK_OK;
+    c->open_pending = false;
+    return wait_mail(c);
+}
+
 // generate_proof(channel) (prover.rs:9): everything is committed to, and every challenge drawn from, the
 // caller's channel `ch`, which may already hold a transcript prefix (main.rs:19 starts from a fresh one).
 int prove_resident(zk_ctx* c, Channel& ch) {
@@ -423,6 +473,7 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     int rc;
     memset(&c->info, 0, sizeof c->info);
     c->info.public_last = c->last;
+    c->pending_top = false;                               // a pending stand-alone tree top: every tree is rebuilt below
     begin_proof(c);
     if ((rc = do_lde(c))) return rc;                      // prover.rs:60-70
     if (c->checks && ((rc = checks_alloc(c)) || (rc = check_interpolant(c)))) return rc;   // prover.rs:64-66
@@ -461,48 +512,27 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     // through ONE launch that takes its work list from host-mapped memory, writes its results there and raises the
     // mailbox flag behind them: no copy commands, no stream synchronisation.  The scatter that completes the device
     // arrays with the host-built parts is enqueued behind it, off the proof's critical path.
-    const size_t nvals = (size_t)Q * (4 + 2 * R);
-    std::vector<const uint32_t*>& vsrc = c->fetch_vals;
-    std::vector<const uint32_t*>& dsrc = c->fetch_nodes;
-    std::vector<uint32_t>& vdev = c->fetch_vdev;
-    std::vector<uint64_t>& ditems = c->fetch_ditems;
-    vsrc.assign(nvals, nullptr); vdev.assign(nvals, 0); dsrc.clear(); ditems.clear();
-    uint64_t* items = c->h_gather_off;
-    size_t nv = 0, ndg = 0, vi = 0;
-    auto want_val = [&](uint32_t layer, size_t x) {
-        if (c->host_vals[layer]) vsrc[vi++] = c->host_vals[layer] + x;
-        else { vdev[vi++] = (uint32_t)nv; items[nv++] = (uint64_t)c->layer_off[layer] + x; }
-    };
-    auto want_path = [&](uint32_t tree, size_t m, size_t leaf) {       // merkle.rs:54-71: the sibling at every depth
-        for (size_t i = leaf + m - 1; i != 0; i = (i - 1) >> 1) {
-            const size_t nd = (i & 1) ? i + 1 : i - 1;
-            if (nd < c->host_node_cnt[tree]) dsrc.push_back(c->host_nodes[tree] + 8 * nd);
-            else { dsrc.push_back(c->h_gather_out + 8 * ndg); ++ndg; ditems.push_back((uint64_t)c->tree_off[tree] + (uint64_t)nd * 8); }
-        }
-    };
+    open_begin(c, (size_t)Q * (4 + 2 * R));
     for (uint32_t k = 0; k < Q; ++k) {
         const size_t x = (size_t)qraws[k] % (N - 2 * B);
-        want_val(0, x);         want_path(0, N, x);
-        want_val(0, x + B);     want_path(0, N, x + B);
-        want_val(0, x + 2 * B); want_path(0, N, x + 2 * B);
-        want_val(1, x);         want_path(1, N, x);
+        open_val(c, 0, x);         open_path(c, 0, N, x);
+        open_val(c, 0, x + B);     open_path(c, 0, N, x + B);
+        open_val(c, 0, x + 2 * B); open_path(c, 0, N, x + 2 * B);
+        open_val(c, 1, x);         open_path(c, 1, N, x);
         for (uint32_t i = 0; i < R; ++i) {
             size_t len = N >> i, xi = x % len, nx = (xi + len / 2) % len;
-            want_val(1 + i, xi); want_path(1 + i, len, xi);
-            want_val(1 + i, nx); want_path(1 + i, len, nx);
+            open_val(c, 1 + i, xi); open_path(c, 1 + i, len, xi);
+            open_val(c, 1 + i, nx); open_path(c, 1 + i, len, nx);
         }
     }
-    if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
-    if (ndg) memcpy(items + nv, ditems.data(), ndg * 8);
-    for (size_t i = 0; i < nvals; ++i)
-        if (!vsrc[i]) vsrc[i] = c->h_gather_out + 8 * ndg + vdev[i];
-    const bool fetch = nv + ndg != 0;
-    if (fetch) HIPCHK(launch_fetch(c->d_layers, c->d_trees, c->dm_gather_off, (uint32_t)nv, (uint32_t)ndg, c->dm_gather_out, c->d_mailbox,
-                                   ++c->mail_seq, c->d_counter, c->stream, prof_of(c)));
-    if ((rc = flush_host_parts(c))) return rc;
+    if ((rc = open_launch(c))) return rc;
+    if ((rc = flush_host_parts(c))) return rc;            // completes the device arrays, behind the fetch: off the critical path
     lap("free term + fetch enqueue");
-    if (fetch && (rc = wait_mail(c))) return rc;
+    if ((rc = open_wait(c))) return rc;
     lap("fetch wait");
+    std::vector<const uint32_t*>& vsrc = c->fetch_vals;
+    std::vector<const uint32_t*>& dsrc = c->fetch_nodes;
+    size_t vi = 0;
     const size_t Lp = c->L;
     std::vector<uint8_t>& buf = c->commit_buf;
     buf.resize(8 + 2 * (8 + 32 * Lp));
@@ -513,7 +543,6 @@ int prove_resident(zk_ctx* c, Channel& ch) {
         return 8 + 32 * plen;
     };
     size_t dpos = 0;
-    vi = 0;
     for (uint32_t q = 0; q < Q; ++q) {
         for (int k = 0; k < 4; ++k) {                         // (u32, AuthPath): prover.rs:274-277
             put32(buf.data(), *vsrc[vi++]);
@@ -536,6 +565,32 @@ int prove_resident(zk_ctx* c, Channel& ch) {
 }
 
 }  // namespace
+
+// The openings of the replicated tail in two steps, so that the sharded prover can have its own fetch in flight beside
+// this one: begin enqueues at most one launch on the tail's stream (what this thread hashed itself during zk_tail_run --
+// tree tops, the small layers and their trees -- is read from the staging buffer), end waits for its flag and copies out.
+namespace zk {
+namespace impl {
+int tail_open_begin(zk_ctx* c, size_t x) {
+    if (!c || !c->tail) return fail(ZK_ERR_INVALID, "tail_open_begin: not a tail context");
+    HIPCHK(hipSetDevice(c->device));
+    open_begin(c, 2 * (size_t)c->R);
+    for (uint32_t i = 0; i < c->R; ++i) {                     // prover.rs:280-289 for the tail layers
+        const size_t len = c->N >> i, xi = x % len, nx = (xi + len / 2) % len;
+        open_val(c, 1 + i, xi); open_path(c, 1 + i, len, xi);
+        open_val(c, 1 + i, nx); open_path(c, 1 + i, len, nx);
+    }
+    return open_launch(c);
+}
+int tail_open_end(zk_ctx* c, uint32_t* vals_out, uint8_t* paths_out) {
+    int rc = open_wait(c);
+    if (rc) return rc;
+    for (size_t i = 0; i < c->fetch_vals.size(); ++i) vals_out[i] = *c->fetch_vals[i];
+    for (size_t i = 0; i < c->fetch_nodes.size(); ++i) digest_words_to_bytes(c->fetch_nodes[i], paths_out + 32 * i);
+    return ZK_OK;
+}
+}  // namespace impl
+}  // namespace zk
 
 // ===========================================================================
 // C ABI
@@ -730,10 +785,15 @@ int zk_ctx_destroy(zk_ctx* c) {
 
 double zk_ctx_setup_ms(const zk_ctx* c) { return c ? c->setup_ms : 0.0; }
 size_t zk_ctx_device_bytes(const zk_ctx* c) { return c ? c->device_bytes : 0; }
-void* zk_ctx_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* zk_ctx_stream(zk_ctx* c) {
+    if (!c) return nullptr;
+    if (c->pending_top && hipSetDevice(c->device) == hipSuccess) (void)settle_pending(c);   // work the caller orders behind the stream sees whole trees
+    return (void*)c->stream;
+}
 int zk_ctx_sync(zk_ctx* c) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
+    if (int rc = settle_pending(c)) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
@@ -830,12 +890,20 @@ int zk_merkle_commit(zk_ctx* c, uint32_t layer, uint8_t root_out[32]) {
     HIPCHK(hipSetDevice(c->device));
     static const bool timing = getenv("ZK_HOST_TIMING") != nullptr;
     const double t0 = now_us();
+    // the top of an earlier stand-alone commitment still waiting in the staging buffer: the same tree is rebuilt now (drop
+    // it), another tree's top goes to the device before its staging space is reused
+    if (c->pending_top && c->pending_tree == layer) c->pending_top = false;
+    int rc = settle_pending(c);
+    if (rc) return rc;
     begin_proof(c);                                      // a stand-alone commitment: nothing staged, no host-side FRI tail
-    int rc = do_merkle(c, layer, true, false);           // Merkle::new (merkle.rs:14); the last levels on this thread
+    rc = do_merkle(c, layer, true, false);               // Merkle::new (merkle.rs:14); the last levels on this thread
     const double t1 = now_us();
     if (!rc) rc = read_commit(c, layer, root_out);
     const double t2 = now_us();
-    if (!rc) rc = flush_host_parts(c);                   // the tree in HBM is complete before any later stage reads it
+    // The root is known.  The device copy of the host-built top (255 nodes) is NOT ordered on the stream here: it would sit
+    // in front of whatever the caller enqueues next (7 us per commitment in a commit loop); settle_pending() orders it
+    // before the first read of the device arrays.
+    if (!rc && c->n_segs) { c->pending_top = true; c->pending_tree = layer; }
     if (timing)
         fprintf(stderr, "[zk timing] merkle_commit(layer %u): enqueue %.1f us, wait for the device %.1f us, host top %.1f us, scatter enqueue %.1f us\n",
                 layer, t1 - t0, c->t_wait, c->t_host_hash, now_us() - t2);
@@ -860,6 +928,7 @@ int zk_layer_read(zk_ctx* c, uint32_t layer, size_t offset, size_t count, uint32
     if (!c || (!out && count)) return fail(ZK_ERR_INVALID, "zk_layer_read: null argument");
     if (layer > c->R + 1 || offset + count > layer_size(c, layer)) return fail(ZK_ERR_INVALID, "zk_layer_read: out of range");
     HIPCHK(hipSetDevice(c->device));
+    if (int prc = settle_pending(c)) return prc;
     HIPCHK(hipMemcpyAsync(out, c->d_layers + c->layer_off[layer] + offset, count * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
@@ -881,6 +950,7 @@ int zk_merkle_node(zk_ctx* c, uint32_t tree, size_t index, uint8_t out[32]) {
     if (!c || !out) return fail(ZK_ERR_INVALID, "zk_merkle_node: null argument");
     if (tree > c->R + 1 || index >= 2 * layer_size(c, tree) - 1) return fail(ZK_ERR_INVALID, "zk_merkle_node: out of range");
     HIPCHK(hipSetDevice(c->device));
+    if (int prc = settle_pending(c)) return prc;
     HIPCHK(hipMemcpyAsync(c->h_small, c->d_trees + c->tree_off[tree] + index * 8, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     digest_words_to_bytes(c->h_small, out);
@@ -891,6 +961,7 @@ int zk_merkle_path(zk_ctx* c, uint32_t tree, size_t leaf, uint8_t* out, size_t* 
     if (!c || !out) return fail(ZK_ERR_INVALID, "zk_merkle_path: null argument");
     if (tree > c->R + 1 || leaf >= layer_size(c, tree)) return fail(ZK_ERR_INVALID, "zk_merkle_path: out of range");
     HIPCHK(hipSetDevice(c->device));
+    if (int prc = settle_pending(c)) return prc;
     std::vector<size_t> nodes;
     path_nodes(layer_size(c, tree), leaf, nodes);
     for (size_t i = 0; i < nodes.size(); ++i) c->h_gather_off[i] = (uint64_t)c->tree_off[tree] + (uint64_t)nodes[i] * 8;
@@ -1056,31 +1127,8 @@ int zk_tail_run(zk_ctx* c, const uint32_t* d_layer0, void* src_stream, zk_channe
 // other in paths_out.  Total digests: sum 2 (L - i).
 int zk_tail_open(zk_ctx* c, size_t x, uint32_t* vals_out, uint8_t* paths_out) {
     if (!c || !c->tail || !vals_out || !paths_out) return fail(ZK_ERR_INVALID, "zk_tail_open: bad argument");
-    HIPCHK(hipSetDevice(c->device));
-    std::vector<uint64_t> voff, doff;
-    std::vector<size_t> nodes;
-    for (uint32_t i = 0; i < c->R; ++i) {
-        size_t len = c->N >> i, xi = x % len, nx = (xi + len / 2) % len;
-        for (size_t leaf : {xi, nx}) {
-            voff.push_back(c->layer_off[1 + i] + leaf);
-            nodes.clear();
-            path_nodes(len, leaf, nodes);
-            for (size_t nd : nodes) doff.push_back((uint64_t)c->tree_off[1 + i] + (uint64_t)nd * 8);
-        }
-    }
-    const size_t nv = voff.size(), ndg = doff.size();
-    if (nv + ndg > c->gather_cap) return fail(ZK_ERR_STATE, "gather capacity exceeded");
-    if (nv == 0) return ZK_OK;
-    memcpy(c->h_gather_off, voff.data(), nv * 8);
-    memcpy(c->h_gather_off + nv, doff.data(), ndg * 8);
-    HIPCHK(hipMemcpyAsync(c->d_gather_off, c->h_gather_off, (nv + ndg) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_gather(c->d_layers, c->d_gather_off, (uint32_t)nv, 1, c->d_gather_out, c->stream, prof_of(c)));
-    HIPCHK(launch_gather(c->d_trees, c->d_gather_off + nv, (uint32_t)ndg, 8, c->d_gather_out + nv, c->stream, prof_of(c)));
-    HIPCHK(hipMemcpyAsync(c->h_gather_out, c->d_gather_out, (nv + ndg * 8) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    memcpy(vals_out, c->h_gather_out, nv * 4);
-    for (size_t i = 0; i < ndg; ++i) digest_words_to_bytes(c->h_gather_out + nv + 8 * i, paths_out + 32 * i);
-    return ZK_OK;
+    int rc = tail_open_begin(c, x);
+    return rc ? rc : tail_open_end(c, vals_out, paths_out);
 }
 int zk_channel_new(zk_channel** out) {
     if (!out) return fail(ZK_ERR_INVALID, "null argument");
