@@ -41,10 +41,10 @@ VALU_PEAK_4CYC_TOPS = SIMDS * 64 * NOMINAL_GHZ * 1e9 / 4 / 1e12          # 39.3 
 # the built code object) and the 4-cycle share of the mix, which gives the mix-weighted issue peak.
 HASH_MODEL = {
     "sha256": {"leaf_ops": 1259, "inner_ops": 2293, "probe_ops": 2246, "four_cycle_share": (940 + 365) / 2262.0},
-    # field hash: probe = ISA loop count (4 + 4 trips of the full-round loops, 22 of the partial-round loop, the straight-line
-    # rest; SQ_INSTS_VALU says 9 103); leaf / inner = SQ_INSTS_VALU per wave of the subtree kernel's two launch shapes solved
-    # for the two unknowns (profiles/r03_pmc/sq_field_counter_collection.csv: 16 L + 15 I = 280 840, 7 I = 64 644)
-    "field": {"leaf_ops": 8895, "inner_ops": 9235, "probe_ops": 9092, "four_cycle_share": 0.45},
+    # field hash (double precision since round 5, csrc/fieldhash_f64.hpp): ISA loop counts (straight-line part + 8 trips of the
+    # full-round loops + 10 trips of the two-partial-round loop; tests/test_kernel_descriptors.py re-counts them from the built
+    # code object).  Every instruction is a double-precision op: the 4-cycle class (measured 4.1 - 5.5 cycles, tools/fh64_probe.hip)
+    "field": {"leaf_ops": 5015, "inner_ops": 5072, "probe_ops": 5046, "four_cycle_share": 1.0},
 }
 def mix_peak_tops(hash_name):
     """Issue peak for this hash's instruction mix at the nominal clock: lanes / (mean cycles per instruction)."""

@@ -53,19 +53,22 @@ def test_no_kernel_uses_scratch(rows):
 
 def test_subtree_kernels_register_budget(rows):
     """512 VGPRs per SIMD lane.  SHA-256 subtree kernels: <= 64 per wave (the 40 KiB of LDS per workgroup, not the
-    registers, sets their four waves per SIMD); field-hash ones: <= 80 (six waves per SIMD)."""
+    registers, sets their four waves per SIMD); field-hash ones (double precision: the state alone is 32 registers): <= 128,
+    i.e. the same four waves per SIMD the LDS allows."""
     sub = [r for r in rows if "merkle_subtree_kernel<" in r["demangled"]]
     assert len(sub) == 14
     for r in sub:
         assert r["agpr"] == 0
         is_field = r["demangled"].split(">(")[0].rstrip().endswith("1")
-        assert r["vgpr"] <= (80 if is_field else 64), (r["demangled"], r["vgpr"])
+        assert r["vgpr"] <= (128 if is_field else 64), (r["demangled"], r["vgpr"])
 
 
 def test_latency_kernels_keep_one_workgroup_per_cu_free_of_spills(rows):
     for r in rows:
         if "merkle_wg_kernel<" in r["demangled"]:
-            assert r["vgpr"] <= 160 and r.get("scratch", 0) == 0, r["demangled"]
+            # one wave per SIMD per workgroup and at most a few workgroups per compute unit: what matters is that nothing spills
+            # (round 5: the continuation phase keeps four more digests live; 176 registers for SHA-256, 236 for the field hash)
+            assert r["vgpr"] <= 256 and r.get("scratch", 0) == 0, r["demangled"]
 
 
 def _loops_of(kd, substring):
@@ -92,13 +95,24 @@ def test_instruction_counts_quoted_by_bench(kd):
     sha = [v for k, v in probes.items() if "<0>" in k][0]
     assert len(sha) == 1 and sha[0][2] == hm["sha256"]["probe_ops"], sha
     fh = sorted([v for k, v in probes.items() if "<1>" in k][0], key=lambda t: t[0])
-    # loops in address order: partial-round loop sits between the two full-round loops, all inside the outer loop
-    outer = max(fh, key=lambda t: t[1] - t[0])
-    inner = [l for l in fh if l is not outer]
-    assert len(inner) == 3
-    full_a, partial, full_b = inner
-    dynamic = (outer[2] - sum(l[2] for l in inner)) + 4 * full_a[2] + 22 * partial[2] + 4 * full_b[2]
+    # loops in address order: the loop over PAIRS of partial rounds (10 trips: rounds 1 .. 20; rounds 0 and 21 are straight-line
+    # code around it, csrc/fieldhash_f64.hpp) sits between the two full-round loops (4 trips each), all inside the outer loop
+    def dynamic_count(loops):
+        loops = sorted(loops, key=lambda t: t[0])
+        outer = max(loops, key=lambda t: t[1] - t[0])
+        inner = [l for l in loops if l is not outer and l[0] >= outer[0] and l[1] <= outer[1] and l[2] > 50]
+        assert len(inner) == 3, loops
+        full_a, partial, full_b = inner
+        return (outer[2] - sum(l[2] for l in inner)) + 4 * full_a[2] + 10 * partial[2] + 4 * full_b[2]
+    dynamic = dynamic_count(fh)
     assert abs(dynamic - hm["field"]["probe_ops"]) <= 0.01 * dynamic, (dynamic, fh)
+    # the subtree kernel's two field-hash loops: one leaf hash, one inner hash
+    subf = list(_loops_of(kd, "merkle_subtree_kernel<zk::PlainSrc, true, 1>").values())[0]
+    big = sorted([l for l in subf if l[2] > 1000], key=lambda t: t[0])
+    assert len(big) == 2, subf
+    leaf_f = dynamic_count([l for l in subf if l[0] >= big[0][0] and l[1] <= big[0][1]])
+    inner_f = dynamic_count([l for l in subf if l[0] >= big[1][0] and l[1] <= big[1][1] and l[2] > 50])
+    assert abs(leaf_f - hm["field"]["leaf_ops"]) <= 0.01 * leaf_f and abs(inner_f - hm["field"]["inner_ops"]) <= 0.01 * inner_f, (leaf_f, inner_f)
     sub = _loops_of(kd, "merkle_subtree_kernel<zk::PlainSrc, true, 0>")
     loops = list(sub.values())[0]
     counts = sorted(l[2] for l in loops)

@@ -1,0 +1,156 @@
+// fieldhash_f64.hpp -- the field-native Merkle hash of fieldhash.hpp (same function, bit for bit) computed in
+// double precision on the device.
+//
+// Why.  P = 3 * 2^30 + 1 > 2^31 leaves 32-bit arithmetic no headroom: every modular addition carries its own
+// correction (4 instructions) and the permutation is ~1 400 additions around ~800 products, 9 092 VALU instructions per
+// hash.  A double holds every integer below 2^53 exactly, v_add_f64 / v_fma_f64 issue at the rate of the 4-cycle integer
+// ops, and an addition is ONE instruction with no correction at all: sums are left to grow (the whole external layer and
+// the round constants run without a single reduction) and only products are reduced, because a product has to be.
+//
+//   mulmod(a, b):  h = a * b (rounded), l = fma(a, b, -h)        a * b = h + l exactly, whatever the magnitudes
+//                  q = rint(h / P), r = fma(-q, P, h) + l         r = a b (mod P), |r| <= 0.75 P + 2^28
+//     exact while |h| < 2^50 P (q is then an integer within 3/4 of h / P, so h - q P is an integer below 2^32 and the
+//     fused multiply-add returns it exactly); here |a b| < 2^76.
+//   The state is kept as SIGNED representatives; magnitudes (bounds, not estimates):
+//     S-box output            <= 0.75 P + 2^28 < 0.84 P
+//     external layer output   <= 5 * 16 * 0.84 P < 2^37.7           (M4 row sums <= 16, then + the four blocks' sum)
+//     S-box input             <  2^37.8, its square < 2^75.6
+//     internal layer          d_i s_i + sum <= 2^14 * 2^37.7 + 2^41.7 < 2^51.7 on entry (exact); s_1 .. s_15 are reduced to
+//                             [-P/2, P/2] every second round, s_12 .. s_15 every round (fh64_internal); s_0 by its S-box
+//   Digest words are canonical residues again: reduce, add P if negative, convert.
+//
+// Used by the throughput kernel (merkle_subtree_kernel<.., HASH = 1>), the leaf / wide levels of the latency kernel and
+// the chain probe; the 16-lane row form of the narrow levels stays in 32-bit Montgomery arithmetic (fieldhash.hpp: it is
+// latency, not throughput, that counts there).  Device only; the host (verifier, tree tops of the sharded prover) keeps
+// the Montgomery code, and tests/test_fieldhash.py compares both with the oracle's plain-residue implementation.
+#pragma once
+#include "fieldhash.hpp"
+
+#if defined(__HIPCC__)
+namespace zk {
+
+struct FieldHashConsts64 {   // canonical residues as doubles
+    double rc_full[kFhRF][kFhT];
+    double rc_part[kFhRP];
+};
+
+inline void fieldhash_make_consts64(const FieldHashConsts& c, FieldHashConsts64& d) {
+    // Montgomery form -> canonical: x R * 1 * R^-1
+    for (int r = 0; r < kFhRF; ++r)
+        for (int i = 0; i < kFhT; ++i) d.rc_full[r][i] = (double)mont_mul(c.rc_full[r][i], 1u);
+    for (int r = 0; r < kFhRP; ++r) d.rc_part[r] = (double)mont_mul(c.rc_part[r], 1u);
+}
+
+constexpr double kPd = 3221225473.0;
+constexpr double kPinvd = 1.0 / 3221225473.0;
+
+// x (an integer, |x| < 2^50 P) -> the representative of x mod P in [-P/2, P/2] (up to the rounding of x / P: |r| < 0.75 P)
+__device__ __forceinline__ double fh64_reduce(double x) {
+    const double q = __builtin_rint(x * kPinvd);
+    return __builtin_fma(-q, kPd, x);
+}
+__device__ __forceinline__ double fh64_mulmod(double a, double b) {
+    const double h = __dmul_rn(a, b);
+    const double l = __builtin_fma(a, b, -h);
+    return fh64_reduce(h) + l;
+}
+__device__ __forceinline__ double fh64_sbox(double x) {
+    const double x2 = fh64_mulmod(x, x);
+    return fh64_mulmod(fh64_mulmod(x2, x2), x);
+}
+// the add / double sequence of fh_m4 with the doublings folded into multiply-adds: 8 instructions per block
+__device__ __forceinline__ void fh64_m4(double& x0, double& x1, double& x2, double& x3) {
+    const double t0 = x0 + x1, t1 = x2 + x3;
+    const double t2 = __builtin_fma(x1, 2.0, t1), t3 = __builtin_fma(x3, 2.0, t0);
+    const double t4 = __builtin_fma(t1, 4.0, t3), t5 = __builtin_fma(t0, 4.0, t2);
+    x0 = t3 + t5; x1 = t5; x2 = t2 + t4; x3 = t4;
+}
+__device__ __forceinline__ void fh64_external(double (&s)[kFhT]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fh64_m4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
+    double col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) col[j] = (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]);
+#pragma unroll
+    for (int i = 0; i < kFhT; ++i) s[i] = s[i] + col[i & 3];
+}
+// I: s_i <- d_i s_i + sum_j s_j, d = (-2, 1, 2, 4, ..., 2^14): one multiply-add per element, and a reduction where the next
+// round needs one.  ALL = true reduces s_1 .. s_15 to [-P/2, P/2] (rho = 0.5 P); ALL = false only s_12 .. s_15, the elements a
+// second unreduced round would push past 2^53:
+//   after a partial round on a reduced state:   |s_i| <= 2^(i-1) rho + 8.4 P  <= 2^40.7   (i <= 11),  |s_0| <= 10 P
+//   the round after it (always ALL = true):      sum <= 2^41.8,  |d_i s_i + sum| <= 2^10 * 2^40.7 + 2^41.8 < 2^50.8, exact
+// s_0 is never reduced here: its S-box in the next round (or the full round's) does it.
+template <bool ALL>
+__device__ __forceinline__ void fh64_internal(double (&s)[kFhT]) {
+    double sum = s[0];
+#pragma unroll
+    for (int i = 1; i < kFhT; ++i) sum += s[i];
+    s[0] = __builtin_fma(s[0], -2.0, sum);
+#pragma unroll
+    for (int i = 1; i < kFhT; ++i) {
+        const double t = __builtin_fma(s[i], (double)(1u << (i - 1)), sum);
+        s[i] = (ALL || i >= 12) ? fh64_reduce(t) : t;
+    }
+}
+template <bool ALL>
+__device__ __forceinline__ void fh64_partial_round(double (&s)[kFhT], double rc) {
+    s[0] = fh64_sbox(s[0] + rc);
+    fh64_internal<ALL>(s);
+}
+__device__ __forceinline__ void fh64_permute(double (&s)[kFhT], const FieldHashConsts64& c) {
+    fh64_external(s);
+#pragma unroll 1
+    for (int r = 0; r < kFhRF / 2; ++r) {
+#pragma unroll
+        for (int i = 0; i < kFhT; ++i) s[i] = fh64_sbox(s[i] + c.rc_full[r][i]);
+        fh64_external(s);
+    }
+    // 22 partial rounds.  The first one takes the external layer's output (up to 2^37.7) and the last one feeds the full
+    // rounds: both reduce everything; in between the rounds alternate (partly reduced, fully reduced).
+    static_assert(kFhRP % 2 == 0 && kFhRP >= 4, "partial-round schedule");
+    fh64_partial_round<true>(s, c.rc_part[0]);
+#pragma unroll 1
+    for (int r = 1; r < kFhRP - 1; r += 2) {
+        fh64_partial_round<false>(s, c.rc_part[r]);
+        fh64_partial_round<true>(s, c.rc_part[r + 1]);
+    }
+    fh64_partial_round<true>(s, c.rc_part[kFhRP - 1]);
+#pragma unroll 1
+    for (int r = kFhRF / 2; r < kFhRF; ++r) {
+#pragma unroll
+        for (int i = 0; i < kFhT; ++i) s[i] = fh64_sbox(s[i] + c.rc_full[r][i]);
+        fh64_external(s);
+    }
+}
+// signed representative -> canonical residue
+__device__ __forceinline__ uint32_t fh64_canonical(double x) {
+    double r = fh64_reduce(x);
+    r = r < 0.0 ? r + kPd : r;
+    return (uint32_t)r;                                    // an integer in [0, P): v_cvt_u32_f64 is exact
+}
+// in: any u32 words (a raw word >= P is the same field element as its residue: field.rs:20-24); out: 8 canonical residues
+__device__ __forceinline__ void fh64_compress(const uint32_t (&in)[kFhT], uint32_t (&out)[8], const FieldHashConsts64& c) {
+    double s[kFhT];
+#pragma unroll
+    for (int i = 0; i < kFhT; ++i) s[i] = (double)in[i];
+    fh64_permute(s, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = fh64_canonical(s[i] + (double)in[i]);
+}
+__device__ __forceinline__ Digest fieldhash_leaf64(uint32_t v, const FieldHashConsts64& c) {
+    const uint32_t in[kFhT] = {v, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1u};
+    Digest d;
+    fh64_compress(in, d.w, c);
+    return d;
+}
+__device__ __forceinline__ Digest fieldhash_inner64(const Digest& l, const Digest& r, const FieldHashConsts64& c) {
+    uint32_t in[kFhT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { in[i] = l.w[i]; in[8 + i] = r.w[i]; }
+    Digest d;
+    fh64_compress(in, d.w, c);
+    return d;
+}
+
+}  // namespace zk
+#endif

@@ -14,7 +14,7 @@
 #include <cstdlib>
 
 #include "field.hpp"
-#include "fieldhash.hpp"
+#include "fieldhash_f64.hpp"
 #include "sha256_quad.hpp"
 #include "sha256.hpp"
 
@@ -503,16 +503,20 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof) {
 // <= 2^11 nodes are finished by a single workgroup that keeps the level in LDS.
 
 // Merkle hash selector: 0 = SHA-256 (merkle.rs:1-2), 1 = field-native hash (fieldhash.hpp).
-__constant__ FieldHashConsts g_fh_consts;
+__constant__ FieldHashConsts g_fh_consts;       // Montgomery form: the 16-lane row form of the narrow levels (fieldhash_inner_row16)
+__constant__ FieldHashConsts64 g_fh_consts64;   // canonical residues as doubles: every other field hash on the device (fieldhash_f64.hpp)
 
 template <int HASH> struct Hasher;
 template <> struct Hasher<0> {
     static __device__ __forceinline__ Digest leaf(uint32_t v) { return sha256_leaf(v); }
     static __device__ __forceinline__ Digest inner(const Digest& l, const Digest& r) { return sha256_inner(l, r); }
 };
+// The field hash runs in double precision on the device (round 5): the same function bit for bit, 0.74 of the time of the
+// 32-bit Montgomery form in a dependent chain (tools/fh64_probe.hip, profiles/r05_fh64_probe.txt): an addition is one
+// instruction instead of four when nothing has to be corrected.
 template <> struct Hasher<1> {
-    static __device__ __forceinline__ Digest leaf(uint32_t v) { return fieldhash_leaf(v, g_fh_consts); }
-    static __device__ __forceinline__ Digest inner(const Digest& l, const Digest& r) { return fieldhash_inner(l, r, g_fh_consts); }
+    static __device__ __forceinline__ Digest leaf(uint32_t v) { return fieldhash_leaf64(v, g_fh_consts64); }
+    static __device__ __forceinline__ Digest inner(const Digest& l, const Digest& r) { return fieldhash_inner64(l, r, g_fh_consts64); }
 };
 
 // Where the leaf values of a tree come from.  The prover fuses the elementwise producer of a layer
@@ -693,14 +697,18 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
 // When the launch reaches the hand-over depth (MailArgs.top; 0 = the root) and a mailbox is given, the
 // digests of that depth are also written to host-mapped memory followed by a sequence number, so the
 // host prover can poll for them instead of paying a blit kernel + stream synchronisation per commitment.
+// j2 > 0 (whole trees only, mail.counter given): the workgroup that finishes LAST goes on with the gridDim.x nodes the
+// launch has produced (<= 2^kWgMaxLog of them) and lowers the tree by j2 more levels -- one launch where the levels of a
+// tree used to need two (round 5: the field hash, which hands nothing to the host, paid 38 latency launches per proof).
 template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t j,
-                                                               MailArgs mail, size_t off) {
-    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^j][2], then the 16 KiB schedule exchange
-    uint32_t* xch = reinterpret_cast<uint32_t*>(lvl + ((size_t)2 << j));
+                                                               MailArgs mail, size_t off, uint32_t j2, uint32_t lds_log) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^lds_log][2], then the 16 KiB schedule exchange
+    uint32_t* xch = reinterpret_cast<uint32_t*>(lvl + ((size_t)2 << lds_log));
     const uint32_t tid = threadIdx.x;
-    const uint32_t cnt = 1u << j;
-    const size_t first = ((size_t)blockIdx.x << j) + off;         // first input of this workgroup (off: see merkle_subtree_kernel)
+    uint32_t cnt = 1u << j;                                       // inputs of this workgroup in the current phase
+    size_t first = ((size_t)blockIdx.x << j) + off;               // first input of this workgroup (off: see merkle_subtree_kernel)
+    uint32_t d_in = depth_in, lv = j;                             // the current phase lowers depth d_in by lv levels
     const size_t in_base = ((size_t)1 << depth_in) - 1;
     QuadLane ql;
     if (HASH == 0) ql = quad_lane(tid);
@@ -734,9 +742,11 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     if (LEAF && mail.dump_src) __threadfence();
     __syncthreads();
 #pragma unroll 1
-    for (uint32_t t = 1; t <= j; ++t) {
+  for (uint32_t phase = 0;; ++phase) {
+#pragma unroll 1
+    for (uint32_t t = 1; t <= lv; ++t) {
         const uint32_t w = cnt >> t;                              // nodes of this level in the workgroup
-        const size_t out_base = (((size_t)1 << (depth_in - t)) - 1) + (first >> t);
+        const size_t out_base = (((size_t)1 << (d_in - t)) - 1) + (first >> t);
         if (HASH == 0 && w <= 64) {
             // Latency-bound level of <= 64 nodes per workgroup: one SHA-256 per FOUR lanes (sha256_quad.hpp: ~1 700
             // instructions on the wave instead of 2 293, no exchange inside the hash), 16 hashes per wave, the waves of
@@ -854,13 +864,48 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
         __syncthreads();
     }
+    if (phase == 1 || j2 == 0) break;
+    // Continuation.  Every workgroup has written its node of depth depth_in - j (the barrier that ends a level has drained
+    // the stores of all its waves); an agent-scope release / acquire on a counter tells the one that arrives last, and that
+    // one alone reads the gridDim.x nodes back (the acquire has invalidated its CU's vector L1) and carries on.
+    __shared__ uint32_t go_on;
+    if (gridDim.x > 1) {
+        // every wave's digest stores have reached L2 before thread 0 releases them to the other compute dies: a wait on this
+        // wave's own stores, then the barrier; the agent-scope release itself (an L2 write-back) is paid ONCE per workgroup,
+        // by the atomic below (256 workgroups x 4 waves of agent-scope fences cost the SHA-256 path 4 us per tree)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t last = 1;
+        if (gridDim.x > 1) {
+            last = __hip_atomic_fetch_add(mail.counter + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            if (last) __hip_atomic_store(mail.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        go_on = last;
+    }
+    __syncthreads();
+    if (!go_on) return;                                            // workgroup-uniform
+    d_in = depth_in - j; lv = j2; cnt = gridDim.x; first = 0;
+    {
+        const size_t base2 = ((size_t)1 << d_in) - 1;
+        Digest dd[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if (tid + u * kWgThreads < cnt) dd[u] = load_digest(nodes, base2 + tid + u * kWgThreads);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if (tid + u * kWgThreads < cnt) lds_store(&lvl[2 * (tid + u * kWgThreads)], dd[u]);
+    }
+    __syncthreads();
+  }
     // The launch that reaches depth mail.top posts its 2^top digests (and, on request, the layer values) to the
     // host: small PCIe writes are slow, so the workgroup that finishes last copies everything with wide stores.
-    if (mail.mailbox && depth_in - j == mail.top && off == 0) {
+    if (mail.mailbox && depth_in - j - j2 == mail.top && off == 0) {
         __shared__ uint32_t is_last;
         if (tid == 0) {
             uint32_t last = 1;
-            if (gridDim.x > 1) {
+            if (gridDim.x > 1 && j2 == 0) {                        // with a continuation only the last workgroup gets here
                 // release: this workgroup's digest (and values) are out; acquire: so are everybody else's
                 last = __hip_atomic_fetch_add(mail.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
                 if (last) __hip_atomic_store(mail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -905,6 +950,10 @@ static hipError_t ensure_fieldhash_consts() {
     FieldHashConsts c;
     fieldhash_make_consts(c);
     e = hipMemcpyToSymbol(HIP_SYMBOL(g_fh_consts), &c, sizeof c);
+    if (e != hipSuccess) return e;
+    static FieldHashConsts64 c64;
+    fieldhash_make_consts64(c, c64);
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_fh_consts64), &c64, sizeof c64);
     if (e == hipSuccess) done[dev] = true;
     return e;
 }
@@ -936,6 +985,30 @@ bool set_merkle_latency_log(uint32_t v) {
     __atomic_store_n(&g_merkle_latency_log, v, __ATOMIC_RELAXED);
     return true;
 }
+
+// ---- how the latency phase of a tree is cut into (phase 1, continuation) -------------------------------------------
+// Microseconds one workgroup, alone on its compute unit, needs for a level of w nodes (every form costs one hash LATENCY per
+// pass: measured per form): SHA-256 one lane per hash 4.6 (256 per pass), main / helper lanes 4.9 (128),
+// four lanes per hash 3.1 (64); field hash one lane per hash in double precision ~20 (256 per pass), a row of 16 lanes 4.5 (16)
+// (from the kernel trace of a field-hash proof, profiles/r05_ab_continuation.txt).
+static double wg_level_us(uint32_t w, int hash) {
+    if (w == 0) return 0.0;
+    if (hash) return w <= 64 ? (double)((w + 15) / 16) * 4.5 : (double)((w + 255) / 256) * 20.0;
+    return w <= 64 ? 3.1 : w <= 128 ? 4.9 : (double)((w + 255) / 256) * 4.6;
+}
+static double wg_phase_us(bool leaf, uint32_t cnt_log, uint32_t levels, int hash, uint32_t blocks) {
+    const uint32_t cnt = 1u << cnt_log;
+    double us = leaf ? (double)((cnt + 255) / 256) * (hash ? 20.0 : 2.6) : 1.0;   // leaf hashes, or the first load
+    for (uint32_t t = 1; t <= levels; ++t) us += wg_level_us(cnt >> t, hash);
+    return blocks > 256 ? us * (double)blocks / 256.0 : us;                        // more workgroups than compute units take turns
+}
+// Build-time A/B switch (ZK_BUILD_DEFS="-DZK_MERKLE_CONTINUATION=0": one launch per <= 10 levels, as rounds 1-4)
+#ifndef ZK_MERKLE_CONTINUATION
+#define ZK_MERKLE_CONTINUATION 1
+#endif
+static constexpr bool g_merkle_continuation = ZK_MERKLE_CONTINUATION != 0;
+constexpr double kContinueUs = 6.0;    // the continuation's release -> count -> acquire -> reload
+constexpr double kLaunchUs = 10.0;     // a further launch on the commit -> challenge -> launch path
 
 // Builds the levels of a heap over 2^log_m leaves that lie above the aligned leaf range
 // [chunk << log_sub, (chunk + 1) << log_sub), from the leaves (leaf_mode) or from the nodes already
@@ -985,25 +1058,49 @@ static hipError_t merkle_build_t(SRC src, double src_bytes, uint32_t log_m, uint
     MailArgs mail = mail_in;
     if (stop != 0 || mail.top >= log_m) mail.top = 0;
     const uint32_t end = stop == 0 ? mail.top : stop;
-    do {
-        // split the remaining levels evenly over the launches (each <= kWgMaxLog)
-        uint32_t span = depth - stop;
-        uint32_t levels = depth - end;
-        uint32_t launches = (levels + kWgMaxLog - 1) / kWgMaxLog;
-        if (launches == 0) launches = 1;
-        uint32_t j = (levels + launches - 1) / launches;
-        uint32_t blocks = 1u << (span - j);
-        size_t sh = ((size_t)2 << j) * sizeof(uint4) + 2 * 16 * 128 * sizeof(uint32_t);
-        ScopedKernelTimer tm(prof, K_MERKLE_TOP, first_bytes(merkle_bytes(leaf, span, j)), s, merkle_ops(leaf, span, j, hash));
+    auto launch_wg = [&](uint32_t j, uint32_t j2) {
+        const uint32_t span = depth - stop;
+        const uint32_t blocks = 1u << (span - j);
+        const uint32_t lds_log = j2 && span - j > j ? span - j : j;       // the continuation holds all `blocks` nodes
+        const size_t sh = ((size_t)2 << lds_log) * sizeof(uint4) + 2 * 16 * 128 * sizeof(uint32_t);
+        ScopedKernelTimer tm(prof, K_MERKLE_TOP, first_bytes(merkle_bytes(leaf, span, j)) + (j2 ? merkle_bytes(false, span - j, j2) : 0.0), s,
+                             merkle_ops(leaf, span, j, hash) + (j2 ? merkle_ops(false, span - j, j2, hash) : 0.0));
         if (hash) {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mail, off_at(depth));
-            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mail, off_at(depth));
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 1>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mail, off_at(depth), j2, lds_log);
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 1>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mail, off_at(depth), j2, lds_log);
         } else {
-            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mail, off_at(depth));
-            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mail, off_at(depth));
+            if (leaf) hipLaunchKernelGGL((merkle_wg_kernel<SRC, true, 0>), dim3(blocks), dim3(kWgThreads), sh, s, src, nodes, depth, j, mail, off_at(depth), j2, lds_log);
+            else hipLaunchKernelGGL((merkle_wg_kernel<PlainSrc, false, 0>), dim3(blocks), dim3(kWgThreads), sh, s, none, nodes, depth, j, mail, off_at(depth), j2, lds_log);
         }
         leaf = false;
-        depth -= j;
+        depth -= j + j2;
+    };
+    // A whole tree with a counter at hand finishes in ONE launch: every workgroup reduces 2^j inputs to a node and the one
+    // that finishes last carries on with those nodes (merkle_wg_kernel: continuation).  (j, j2) is the split the level
+    // cost model below likes best; a lone workgroup is a bad way to hash a small tree (2^10 leaves of the field hash:
+    // 142 us in one workgroup, ~50 us as 32 workgroups and a continuation).
+    const bool may_continue = stop == 0 && mail.counter != nullptr && g_merkle_continuation;
+    do {
+        const uint32_t span = depth - stop;
+        const uint32_t levels = depth - end;
+        // without a continuation: the remaining levels split evenly over launches of <= kWgMaxLog levels; this launch takes jn
+        const uint32_t launches = levels ? (levels + kWgMaxLog - 1) / kWgMaxLog : 1;
+        const uint32_t jn = (levels + launches - 1) / launches;
+        uint32_t best_j = jn, best_j2 = 0;
+        if (may_continue && levels <= 2 * kWgMaxLog) {
+            // cost of the plain way to depth `end` (a further launch costs the host an enqueue on the commit -> challenge -> launch
+            // path; only the two-launch case is compared, deeper trees take the plain way first)
+            double best = wg_phase_us(leaf, jn, jn, hash, 1u << (span - jn));
+            if (launches == 2 && span - jn <= kWgMaxLog) best += kLaunchUs + wg_phase_us(false, span - jn, levels - jn, hash, 1);
+            else if (launches > 1) best = 0.0;                                  // not modelled: keep the plain way
+            for (uint32_t j = 1; j < levels && j <= kWgMaxLog; ++j) {
+                const uint32_t j2 = levels - j;
+                if (j2 > kWgMaxLog || span - j > kWgMaxLog) continue;          // the continuation keeps 2^(span - j) nodes in LDS
+                const double us = wg_phase_us(leaf, j, j, hash, 1u << (span - j)) + kContinueUs + wg_phase_us(false, span - j, j2, hash, 1);
+                if (us < best) { best = us; best_j = j; best_j2 = j2; }
+            }
+        }
+        launch_wg(best_j, best_j2);
     } while (depth > end);
     return hipGetLastError();
 }

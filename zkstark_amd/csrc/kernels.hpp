@@ -26,11 +26,12 @@ enum KernelClass : int {
 constexpr double kShaLeafOps = 1259.0;    // VALU instructions of one leaf hash (sha256.hpp, measured from the ISA)
 constexpr double kShaInnerOps = 2293.0;
 constexpr double kNttOpsPerElement = 57.0;  // VALU instructions per element of a radix-128 pass (SQ_INSTS_VALU, round 4: 904.5 per wave of 16 elements/lane; round 3: 78)
-// field-native hash: one permutation per hash.  SQ_INSTS_VALU per wave of the subtree kernel's leaf launch (16 leaf + 15
-// inner hashes) and inner launch (7 inner hashes), solved for the two (profiles/r03_pmc/); the chain probe's loop body is
-// 9 092 by ISA count (tools/kernel_descriptors.py --loops), 9 103 by the counter
-constexpr double kFieldLeafOps = 8895.0;
-constexpr double kFieldInnerOps = 9235.0;
+// field-native hash: one permutation per hash, in double precision since round 5 (fieldhash_f64.hpp).  VALU instructions by
+// ISA loop count (tools/kernel_descriptors.py --loops: straight-line part + 8 trips of the full-round loops at 364 + 10 trips
+// of the two-partial-round loop at 179): leaf / inner hash of the subtree kernel, 5 046 for the chain probe's loop body.
+// (32-bit Montgomery form, rounds 1-4: 8 895 / 9 235 / 9 092.)
+constexpr double kFieldLeafOps = 5015.0;
+constexpr double kFieldInnerOps = 5072.0;
 
 struct Profiler {
     uint32_t mask = 0;
