@@ -630,6 +630,24 @@ def test_batch_prover_matches_oracle(zk, orc, log_n, log_b, log_batch):
         proofs[p].verify()
 
 
+def test_batch_prover_at_the_benchmark_domain_2e24(zk, orc):
+    """Throughput mode at the metric's own domain (bench.py: batched_2e24): two 2^24 proofs in lockstep.  Proof 0 is compared with
+    the ORACLE byte for byte (the oracle proves 2^24 in a few seconds), proof 1 with zk_prove of its own trace (that prover is
+    itself oracle-checked at this size: test_config3_*), and both pass the strict verifier (prover.rs:9-293 per proof)."""
+    log_n, log_b = 21, 3
+    seeds = [3141592, 3141593]
+    with zk.BatchContext(log_n, log_b, 1) as bc:
+        bc.gen_fibsq([1, 1], seeds)
+        proofs = bc.prove()
+    want = orc.prove(log_n, log_b, 1, seeds[0], want_vectors=False)
+    assert want.rc == 0 and proofs[0].data == want.proof and proofs[0].state == want.state
+    with zk.Context(log_n, log_b) as ctx:
+        one = ctx.prove(zk.trace_fibsq((1 << log_n) - 1, 1, seeds[1]))
+    assert proofs[1].data == one.data and proofs[1].state == one.state and proofs[1].public_last == one.public_last
+    for p in proofs:
+        p.verify(strict=True)
+
+
 @pytest.mark.parametrize("hash_name,q", [("sha256", 3), ("field", 1), ("field", 2)])
 def test_batch_prover_queries_and_field_hash(zk, orc, hash_name, q):
     """The batch honours the same settings as a context: q decommitment queries, field-native Merkle hash."""
