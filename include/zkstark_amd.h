@@ -298,7 +298,7 @@ int zk_tail_open(zk_ctx *tail, size_t x, uint32_t *vals_out, uint8_t *paths_out)
  * LDE, composition and every fold run the single-GPU kernels with no communication.  The only exchange is the
  * commitment: one all-to-all per committed layer turns the cyclic layout into contiguous leaf blocks (the transpose
  * of a four-step NTT over the ranks), each rank hashes its subtree, the `world` subtree roots are exchanged and the
- * top log2(world) levels are hashed on the host.  Layers below 2^22 values are replicated and finished by every rank
+ * top log2(world) levels are hashed on the host.  Layers below 2^21 values (2^20 from 4 ranks on) are replicated and finished by every rank
  * (zk_tail_*).  Every rank runs the same transcript and returns the same proof bytes, identical to zk_prove's.
  *
  * Transport.  By default the collectives are RCCL's (librccl.so.1 is loaded at run time; grouped ncclSend/ncclRecv for
@@ -316,7 +316,7 @@ typedef struct zk_shard_transport {
     int (*all_gather)(void *user, const uint32_t *send, uint32_t *recv, size_t words, void *stream);
 } zk_shard_transport;
 typedef struct zk_shard_options {   /* zero = default */
-    uint32_t min_layer_log;     /* a FRI layer stays sharded while it has >= 2^this values in total (22) */
+    uint32_t min_layer_log;     /* a FRI layer stays sharded while it has >= 2^this values in total (21; 20 from 4 ranks on) */
     uint32_t min_chunk_log;     /* ... and >= 2^this leaves per (rank, peer) piece (14) */
     uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (21) */
     int force_collectives;      /* run the collectives even with world = 1 (exercises the transport on one GPU) */

@@ -576,7 +576,7 @@ void orc_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
 /* Field-native Merkle hash (BASELINE.json configs[4])  */
 /* ======================================================================== */
 /* The reference has only SHA-256 (merkle.rs:1-2).  This Poseidon2-style permutation over GF(P)
- * is the build's own definition ("parity: self-defined"); the spec is DESIGN.md section 8 and
+ * is the build's own definition ("parity: self-defined"); the spec is DESIGN.md section 7 and
  * this code.  Width 16, S-box x^5 (gcd(5, P-1) = 1), 8 full + 22 partial rounds, external layer
  * circ(2 M4, M4, M4, M4), internal layer J + diag(d).  A performance stand-in, not a vetted
  * instance.  Digest = first 8 state words of perm(state) + state. */

@@ -18,7 +18,7 @@ shift w h^r.  The only exchange step is the commitment: Merkle leaves are in nat
 per committed layer ONE all-to-all of the 4-byte values turns the cyclic layout into contiguous
 blocks of m/G leaves, each rank hashes its subtree, the G subtree roots (32 B each) are
 all-gathered and the top log2(G) levels are hashed on the host by every rank.  Once a layer has
-fewer than 2^min_layer_log values in total (default 2^22: a sharded commitment carries ~250 us of
+fewer than 2^min_layer_log values in total (default: zk_shard_plan's, 2^21 or 2^20: a sharded commitment carries ~70 us of
 fixed cost -- two collectives, two device-to-host reads, the latency phase of the subtree -- which
 is what hashing 2^21 leaves redundantly costs) or fewer than 2^min_chunk_log leaves per (rank, peer)
 chunk, it is all-gathered once and the remaining layers are folded and committed on every rank in
@@ -382,8 +382,9 @@ class ShardedProver:
     """generate_proof (prover.rs:9-293) for one proof spread over comm.world ranks."""
 
     def __init__(self, log_n, log_blowup, comm, backend, min_chunk_log=None, overlap_min_log=0, min_layer_log=None, use_board=True):
+        default_layout = min_layer_log is None and min_chunk_log is None      # zk_shard_plan's own thresholds (0 = default)
         if min_layer_log is None:                      # an explicit chunk threshold alone decides (tests shard tiny domains)
-            min_layer_log = 22 if min_chunk_log is None else 0
+            min_layer_log = 0
         if min_chunk_log is None:
             min_chunk_log = 14
         self.log_n, self.log_b, self.comm, self.be = log_n, log_blowup, comm, backend
@@ -399,7 +400,7 @@ class ShardedProver:
         # is the one statement of the layout, shared with the native prover (in zk_shard_options 0 selects the default, so the
         # smallest explicit threshold is 1: pieces of two leaves).
         from zkstark_amd.host import shard_plan
-        plan = shard_plan(G, log_n, log_blowup, min_layer_log=max(min_layer_log, 1), min_chunk_log=max(min_chunk_log, 1),
+        plan = shard_plan(G, log_n, log_blowup, min_layer_log=0 if default_layout else max(min_layer_log, 1), min_chunk_log=max(min_chunk_log, 1),
                           overlap_min_log=overlap_min_log, force_collectives=bool(getattr(comm, "force", False)))
         self.plan = plan
         self.n_sharded = plan["sharded_layers"]

@@ -249,7 +249,8 @@ def test_shard_plan_is_the_one_layout(zk):
     """zk_shard_plan (no GPU): the layout both the native sharded prover and the torch.distributed mirror follow.
     The benchmark's weak-scaling configurations, the byte formula of DESIGN.md section 6, and the mirror's view of it."""
     # bench.py --gpus 2 / 4 / 8 (2^24 elements per GPU, production thresholds): GPU tests assert the same numbers on the prover's stats
-    for world, log_n, want_sharded, want_chunked in ((2, 22, 4, 4), (4, 23, 5, 3), (8, 24, 6, 2), (8, 21, 3, 0), (1, 21, 3, 0)):
+    # (round 5: layers of >= 2^21 values stay distributed, >= 2^20 from 4 ranks on; the last rows are the strong shape of bench.py)
+    for world, log_n, want_sharded, want_chunked in ((2, 22, 5, 4), (4, 23, 7, 3), (8, 24, 8, 2), (8, 21, 5, 0), (4, 21, 5, 0), (2, 21, 4, 3), (1, 21, 4, 0)):
         pl = zk.shard_plan(world, log_n, 3)
         assert (pl["sharded_layers"], pl["chunked_layers"]) == (want_sharded, want_chunked), (world, log_n, pl)
         assert pl["tail_rounds"] == log_n - want_sharded and pl["log_chunks"] == 2
@@ -265,7 +266,7 @@ def test_shard_plan_is_the_one_layout(zk):
     assert pl["chunked_mask"] & 1 and pl["piece_log"][0] == 10 and not (pl["chunked_mask"] >> 2) & 1
     # zk_shard_options.plain_collectives (the fall-back rung of bench.py): the same distributed layers, nothing in chunks
     pl = zk.shard_plan(8, 24, 3, plain_collectives=True)
-    assert pl["sharded_layers"] == 6 and pl["chunked_mask"] == 0 and pl["chunked_layers"] == 0 and pl["overlap_min_log"] == 99
+    assert pl["sharded_layers"] == 8 and pl["chunked_mask"] == 0 and pl["chunked_layers"] == 0 and pl["overlap_min_log"] == 99
     assert pl["all_to_all_bytes"] == zk.shard_plan(8, 24, 3)["all_to_all_bytes"]
     for bad in ((3, 12, 3), (16, 12, 3), (2, 3, 3), (4, 4, 2)):
         with pytest.raises(zk.ZkError) as e:

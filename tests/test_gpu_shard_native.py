@@ -273,7 +273,7 @@ def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
 def test_shard_two_ranks_production_sizes_2e25(orc):
     """Two ranks at the per-rank size of the weak-scaling benchmark (2^24 elements each, domain 2^25) with the
     production thresholds: f, cp and the next two FRI layers go through the chunked exchange (pieces of 2^23 ... 2^21 words),
-    the rest through the replicated tail.  Every byte of the proof and all 24 roots against the oracle."""
+    the 2^21-value layer through a plain one, the rest through the replicated tail.  Every byte of the proof and all 24 roots against the oracle."""
     log_n, world = 22, 2
     want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
     assert want.rc == 0
@@ -281,13 +281,13 @@ def test_shard_two_ranks_production_sizes_2e25(orc):
     for rank, data, state, roots, st in out:
         assert data == want.proof and state == want.state, f"rank {rank}"
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
-        assert st["sharded_layers"] == 4 and st["chunked_layers"] == 4 and st["root_board"] == 1
+        assert st["sharded_layers"] == 5 and st["chunked_layers"] == 4 and st["root_board"] == 1
 
 
 def test_shard_four_ranks_production_sizes_2e26(orc):
     """Four ranks, 2^24 elements each (domain 2^26, the size of BASELINE.json configs[3]), production thresholds:
     chunked exchange for the pieces of 2^22 and 2^21 words (f, cp, the next FRI layer), single exchanges below, replicated
-    tail from 2^21 values."""
+    tail from 2^19 values (layers of >= 2^20 values stay distributed from 4 ranks on)."""
     log_n, world = 23, 4
     want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
     assert want.rc == 0
@@ -296,8 +296,8 @@ def test_shard_four_ranks_production_sizes_2e26(orc):
     for rank, data, state, roots, st in out:
         assert data == want.proof and state == want.state, f"rank {rank}"
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
-        assert st["sharded_layers"] == 5 and st["chunked_layers"] == 3 and st["root_board"] == 1
-        words = N + sum(N >> rho for rho in range(5))
+        assert st["sharded_layers"] == 7 and st["chunked_layers"] == 3 and st["root_board"] == 1
+        words = N + sum(N >> rho for rho in range(7))
         assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world      # 12 N-ish bytes in total, (G-1)/G of it to peers
 
 
@@ -363,7 +363,7 @@ def test_shard_ranks_as_threads_of_one_process(threads_check, orc, world, log_n,
 def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
     """The exact configuration `bench.py --gpus 8` proves: domain 2^27, eight ranks of 2^24 elements each, production
     thresholds (0 = defaults) -- here as eight threads on one GPU.  Every rank's bytes equal the single-GPU prover's at
-    2^27 (itself oracle-pinned up to 2^24 and by the strict verifier here); 6 distributed layers; f and cp (pieces of 2^21 words) in chunks."""
+    2^27 (itself oracle-pinned up to 2^24 and by the strict verifier here); 8 distributed layers (down to 2^20 values: round 5); f and cp (pieces of 2^21 words) in chunks."""
     import subprocess
     import torch
     free, _ = torch.cuda.mem_get_info()
@@ -373,8 +373,8 @@ def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
     assert out.returncode == 0, out.stdout + out.stderr
     from zkstark_amd import _lib
     plen = _lib.load().zk_proof_data_len(24, 3)
-    assert f"threads ok: world 8, {plen} proof bytes on every rank equal zk_prove; sharded layers 6, chunked 2, board 1" in out.stdout
-    # 12 N-ish bytes in total: f and FRI layers 0..5, 4 bytes per element, (G-1)/G of it to peers
+    assert f"threads ok: world 8, {plen} proof bytes on every rank equal zk_prove; sharded layers 8, chunked 2, board 1" in out.stdout
+    # 12 N-ish bytes in total: f and FRI layers 0..7, 4 bytes per element, (G-1)/G of it to peers
     N = 1 << 27
-    words = N + sum(N >> rho for rho in range(6))
+    words = N + sum(N >> rho for rho in range(8))
     assert f"all-to-all bytes per rank {4.0 * words / 8 * 7 / 8:.0f}" in out.stdout

@@ -22,7 +22,7 @@
 // Used by the throughput kernel (merkle_subtree_kernel<.., HASH = 1>), the leaf / wide levels of the latency kernel and
 // the chain probe; the 16-lane row form of the narrow levels stays in 32-bit Montgomery arithmetic (fieldhash.hpp: it is
 // latency, not throughput, that counts there).  Device only; the host (verifier, tree tops of the sharded prover) keeps
-// the Montgomery code, and tests/test_fieldhash.py compares both with the oracle's plain-residue implementation.
+// the Montgomery code; the tests compare both with an independent plain-residue implementation.
 #pragma once
 #include "fieldhash.hpp"
 

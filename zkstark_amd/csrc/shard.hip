@@ -126,7 +126,7 @@ struct zk_shard {
     std::vector<hipEvent_t> ev_pool;
     double tail_ms_acc = 0;
     // layout
-    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 21;
+    uint32_t min_layer_log = 21, min_chunk_log = 14, overlap_min_log = 21;   // zk_shard_plan has the defaults in force
     static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
     uint32_t n_sharded = 1, tail_rounds = 0, chunked_mask = 0;   // zk_shard_plan
     zk_dom* dom_loc = nullptr;
@@ -781,7 +781,12 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
     while ((1 << lg) < world) ++lg;
     if ((1 << lg) != world || lg > log_b)
         return fail(ZK_ERR_INVALID, "zk_shard_plan: world size %d must be a power of two dividing the blow-up %u", world, 1u << log_b);
-    uint32_t min_layer_log = 22, min_chunk_log = 14, overlap_min_log = 21;
+    // Defaults (round 5).  A sharded commitment costs ~45 us more than the same layer inside the fused replicated tail (one rank
+    // through RCCL, tools/shard_min_layer.py: +43, +26, +10 us per extra sharded layer) plus an all-to-all of a few hundred KiB
+    // per link (latency, ~20-30 us); replicating a layer costs every rank the whole layer's hashing, (1 - 1/G) of which sharding
+    // saves: 2^21 leaves 235 us, 2^20 145 us, 2^19 100 us.  So 2^21 values pay at every G, 2^20 from G = 4 on.  (Rounds 1-4: 22,
+    // from a fixed cost of ~250 us measured before the committer, the board and the one-launch decommitment existed.)
+    uint32_t min_layer_log = world >= 4 ? 20 : 21, min_chunk_log = 14, overlap_min_log = 21;
     bool force = false;
     if (opt) {
         if (opt->min_layer_log) min_layer_log = opt->min_layer_log;
