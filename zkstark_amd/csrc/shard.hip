@@ -226,10 +226,23 @@ int rccl_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* re
     // the all-to-all of the four-step transpose: every pair exchanges one piece, all 7 xGMI links busy at once.
     // A failed Send / Recv must not leave the thread's group open (every later RCCL call would be undefined):
     // the group is always ended, then the first error is reported.
+    // This rank's own piece never leaves the GPU: a plain device copy in stream order (RCCL moves a send / receive pair of a
+    // rank with itself through its transport kernel at ~0.14 TB/s: 1.4 ms of exchanges per 2^24 proof at one rank; at G ranks
+    // it is 1/G of every exchange).  -DZK_SHARD_RCCL_SELF at build time keeps it inside the group.
+    // With ONE rank (collectives forced: the rehearsal of this code path on a one-GPU box) the pair stays inside the group,
+    // so that ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd are exercised by every one-GPU test and bench rehearsal.
+#ifndef ZK_SHARD_RCCL_SELF
+    const bool self_copy = s->G > 1;
+#else
+    const bool self_copy = false;
+#endif
+    if (self_copy && send[s->rank] != recv[s->rank])
+        HIPCHK(hipMemcpyAsync(recv[s->rank], send[s->rank], words * 4, hipMemcpyDeviceToDevice, st));
     NCCLCHK(s, s->rccl->GroupStart());
     ncclResult_t first = ncclSuccess;
     int bad_peer = -1;
     for (int p = 0; p < s->G && first == ncclSuccess; ++p) {
+        if (self_copy && p == s->rank) continue;
         ncclResult_t r = s->rccl->Send(send[p], words, ncclUint32, p, comm, st);
         if (r == ncclSuccess) r = s->rccl->Recv(recv[p], words, ncclUint32, p, comm, st);
         if (r != ncclSuccess) { first = r; bad_peer = p; }
