@@ -163,6 +163,8 @@ if os.environ.get("ZK_BENCH_RUNG_BUDGET_S"):                 # rehearsals shorte
 RUN_BUDGET_S = 150.0                   # the timed proofs of the headline (after the first proof)
 LEG_BUDGET_S = 60.0                    # every secondary leg after the headline (parity, lde_commit, strong leg, configs[3]): a SOFT
                                        # deadline -- the line is printed without a leg that hangs
+if os.environ.get("ZK_BENCH_LEG_BUDGET_S"):                  # rehearsals shorten it (tests/test_bench_cli.py)
+    LEG_BUDGET_S = float(os.environ["ZK_BENCH_LEG_BUDGET_S"])
 RENDEZVOUS_BUDGET_S = 150.0            # gloo rendezvous of the workers: no RCCL in it, but the ranks' first `import torch` on a fresh
                                        # box can finish a minute apart, and a rank that gives up early would split the generations
 SHARD_TIMEOUT_S = 20.0                 # zk_shard_options.timeout_s: every host-side wait on a peer inside the library
@@ -955,6 +957,8 @@ def main():
             sl = args.log_n
             key = f"strong_2e{sl + log_b}"
             soft(key)
+            if os.environ.get("ZK_BENCH_SIMULATE_LEG_HANG") == "strong":     # rehearsal: a collective of this leg never returns
+                time.sleep(3600)
             try:
                 tr_s = trace if sl == log_n else zk.trace_fibsq((1 << sl) - 1)
                 with shard_ctx(kind, plain, sl, transport) as sps:

@@ -163,6 +163,24 @@ def test_bench_sharded_transports_one_rank(env_extra, want_transport):
 
 
 @pytest.mark.gpu
+def test_bench_a_secondary_leg_that_hangs_costs_only_that_leg():
+    """Legs after the headline run under a soft deadline: when one hangs (here: the strong-scaling leg, simulated), rank 0
+    prints the line with everything measured so far, names the missing leg, and every rank exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ZK_BENCH_FORCE_SHARDED="1", ZK_BENCH_STRONG_LEG="1", ZK_BENCH_SIMULATE_LEG_HANG="strong", ZK_BENCH_LEG_BUDGET_S="6",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "16"],
+                         capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["parity_checked"] is True and rec["value"] > 0 and "lde_commit_sharded" in rec      # the legs before it are there
+    assert "strong_2e19" not in rec and any("strong_2e19" in x for x in rec["legs_skipped"])
+    assert "WATCHDOG: secondary leg" in out.stderr
+
+
+@pytest.mark.gpu
 def test_bench_strong_scaling_and_exact_config4_rehearsal():
     """--scaling strong keeps the single-GPU domain; with N in {2, 4, 8} the line also carries BASELINE configs[3] at exactly
     domain 2^26 (here: two ranks sharing the GPU, host-staged), whose root is the committed golden value."""

@@ -16,7 +16,7 @@ if [ -f $O/bench_sharded_1rank.json ]; then
     cp $O/bench_rehearsal_hang.json $P/r05_bench_rehearsal_hang.json; grep -E "^\[bench\]" $O/bench_rehearsal_hang.err > $P/r05_bench_rehearsal_hang.log || true
     { echo "# tests/shard_threads_check.c <world> <log_n> 3 0 0 0 3, three repetitions: the native sharded prover with the ranks as THREADS of one process on ONE MI355X"
       echo "# (device-to-device transport standing in for xGMI; the GPU is shared, so a figure is the device work of all ranks together).  Weak-scaling sizes, 2^24 elements per rank."
-      echo "# Round 3: 48.03 / 24.15 / 13.09 ms; round 4: 51.05 / 23.45 / 12.00 ms (the 8-rank figure did not reproduce: docs/LOG.md, round 5 item 2)."
+      echo "# Round 3: 48.03 / 24.15 / 13.09 ms; round 4: 51.05 / 23.45 / 12.00 ms (the 8-rank figure did not reproduce: docs/LOG.md, round 5 item 2).  Final build of round 5: layers of >= 2^21 values distributed (>= 2^20 from 4 ranks on)."
       cat $O/shard_threads_timing.txt; } > $P/r05_shard_threads_timing.txt
     { echo "# the STRONG shape on the same harness: one 2^24 proof over 8 / 4 / 2 ranks (threads of one process sharing one GPU), min_layer_log swept."
       echo "# 'per rank' = total / G is a LOWER bound of a rank's time on its own GPU: the replicated parts (the tail below min_layer_log, the size-n iNTT, the decommitment) are in it G times and do not shrink with G."
