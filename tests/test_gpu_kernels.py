@@ -648,6 +648,45 @@ def test_batch_prover_at_the_benchmark_domain_2e24(zk, orc):
         p.verify(strict=True)
 
 
+def test_batch_setters_are_refused_while_a_prove_runs(zk):
+    """One batch is used from one host thread at a time; a setter that arrives from another thread while zk_batch_prove runs
+    is refused with ZK_ERR_STATE instead of replacing the pool / buffers under the running proof, and the
+    proofs of that run are unharmed."""
+    import threading
+    from zkstark_amd import _lib
+    lib = _lib.load()
+    log_n, log_b, log_batch = 16, 3, 4
+    a1s = [3141592 + p for p in range(1 << log_batch)]
+    with zk.BatchContext(log_n, log_b, log_batch) as bc:
+        bc.gen_fibsq([1] * len(a1s), a1s)
+        first, _ = bc.prove_raw()
+        seen, out, stop = [], {}, threading.Event()
+
+        def prover():
+            done = 0
+            while done < 6:
+                try:
+                    out["last"] = bc.prove_raw()[0]
+                    done += 1
+                except zk.ZkError as e:                     # a setter of the other thread held the batch at that instant
+                    assert e.code == -4
+                    seen.append(-4)
+            stop.set()
+
+        t = threading.Thread(target=prover)
+        t.start()
+        while not stop.is_set():
+            seen.append(lib.zk_batch_set_threads(bc._h, 3))
+            seen.append(lib.zk_batch_set_queries(bc._h, 1))
+        t.join()
+        assert -4 in seen                                   # ZK_ERR_STATE at least once while a prove was in flight
+        assert set(seen) <= {0, -4}
+        assert (out["last"] == first).all()
+        assert lib.zk_batch_set_threads(bc._h, 3) == 0      # idle again: accepted
+        again, _ = bc.prove_raw()
+        assert (again == first).all()
+
+
 @pytest.mark.parametrize("hash_name,q", [("sha256", 3), ("field", 1), ("field", 2)])
 def test_batch_prover_queries_and_field_hash(zk, orc, hash_name, q):
     """The batch honours the same settings as a context: q decommitment queries, field-native Merkle hash."""

@@ -246,24 +246,25 @@ int zk_batch_create(int device, uint32_t log_n, uint32_t log_b, uint32_t log_bat
 size_t zk_batch_size(const zk_batch* b) { return b ? b->batch : 0; }
 // One batch is used from one host thread at a time (include/zkstark_amd.h); a setter that arrives while zk_batch_prove runs on
 // another thread would pull the pool, the gather buffers or the traces from under it, so it is refused instead.
-static int batch_idle(const zk_batch* b, const char* who) {
-    return b->busy.load(std::memory_order_acquire) ? fail(ZK_ERR_STATE, "%s: a zk_batch_prove is running on this batch", who) : (int)ZK_OK;
-}
 struct BusyScope {
     zk_batch* b; bool mine;
     explicit BusyScope(zk_batch* b_) : b(b_) { bool expected = false; mine = b->busy.compare_exchange_strong(expected, true, std::memory_order_acq_rel); }
     ~BusyScope() { if (mine) b->busy.store(false, std::memory_order_release); }
 };
+// (the setters hold the same flag for their own duration, so a prove that starts while a setter replaces the pool is refused too)
+#define ZK_BATCH_EXCLUSIVE(b, who)                                                                       \
+    BusyScope _excl(b);                                                                                  \
+    if (!_excl.mine) return fail(ZK_ERR_STATE, "%s: another call (zk_batch_prove or a setter) is running on this batch", who)
 int zk_batch_set_host_levels(zk_batch* b, int on) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
-    if (int brc = batch_idle(b, "zk_batch_set_host_levels")) return brc;
+    ZK_BATCH_EXCLUSIVE(b, "zk_batch_set_host_levels");
     if (b->single) return zk_ctx_set_host_levels(b->single, on && host_sha_available() ? 8 : 0, on && host_sha_available() ? 9 : 0);
     b->host_levels = on != 0 && host_sha_available();
     return ZK_OK;
 }
 int zk_batch_set_threads(zk_batch* b, uint32_t threads) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
-    if (int brc = batch_idle(b, "zk_batch_set_threads")) return brc;
+    ZK_BATCH_EXCLUSIVE(b, "zk_batch_set_threads");
     if (threads < 1 || threads > 64) return fail(ZK_ERR_INVALID, "zk_batch_set_threads: need 1 <= threads <= 64");
     if (b->single || !b->pool || b->pool->workers() == threads - 1) return ZK_OK;
     Pool* np = new (std::nothrow) Pool(threads - 1);
@@ -274,7 +275,7 @@ int zk_batch_set_threads(zk_batch* b, uint32_t threads) {
 }
 int zk_batch_set_queries(zk_batch* b, uint32_t n_queries) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
-    if (int brc = batch_idle(b, "zk_batch_set_queries")) return brc;
+    ZK_BATCH_EXCLUSIVE(b, "zk_batch_set_queries");
     if (n_queries < 1 || n_queries > 16) return fail(ZK_ERR_INVALID, "zk_batch_set_queries: need 1 <= n_queries <= 16");
     if (b->single) { b->queries = n_queries; return zk_ctx_set_queries(b->single, n_queries); }
     HIPCHK(hipSetDevice(b->device));
@@ -283,7 +284,7 @@ int zk_batch_set_queries(zk_batch* b, uint32_t n_queries) {
 }
 int zk_batch_set_hash(zk_batch* b, int hash_kind) {
     if (!b) return fail(ZK_ERR_INVALID, "null batch");
-    if (int brc = batch_idle(b, "zk_batch_set_hash")) return brc;
+    ZK_BATCH_EXCLUSIVE(b, "zk_batch_set_hash");
     if (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) return fail(ZK_ERR_INVALID, "zk_batch_set_hash: unknown hash %d", hash_kind);
     b->hash = hash_kind;
     if (b->single) return zk_ctx_set_hash(b->single, hash_kind);
@@ -292,9 +293,13 @@ int zk_batch_set_hash(zk_batch* b, int hash_kind) {
 size_t zk_batch_device_bytes(const zk_batch* b) { return b ? b->device_bytes : 0; }
 
 // traces: [batch][n-1] canonical residues on the host (prover.rs:32-39 per proof)
+static int set_traces_exclusive(zk_batch* b, const uint32_t* traces);
 int zk_batch_set_traces(zk_batch* b, const uint32_t* traces) {
     if (!b || !traces) return fail(ZK_ERR_INVALID, "zk_batch_set_traces: null argument");
-    if (int brc = batch_idle(b, "zk_batch_set_traces")) return brc;
+    ZK_BATCH_EXCLUSIVE(b, "zk_batch_set_traces");
+    return set_traces_exclusive(b, traces);
+}
+static int set_traces_exclusive(zk_batch* b, const uint32_t* traces) {      // the caller holds the batch
     if (b->single) {
         int rc = zk_trace_upload(b->single, traces, b->n - 1);
         if (rc) return rc;
@@ -315,11 +320,11 @@ int zk_batch_set_traces(zk_batch* b, const uint32_t* traces) {
 // Fibonacci-square traces generated on the device from per-proof seeds (one lane per trace).
 int zk_batch_gen_fibsq(zk_batch* b, const uint32_t* a0, const uint32_t* a1) {
     if (!b || !a0 || !a1) return fail(ZK_ERR_INVALID, "zk_batch_gen_fibsq: null argument");
-    if (int brc = batch_idle(b, "zk_batch_gen_fibsq")) return brc;
+    ZK_BATCH_EXCLUSIVE(b, "zk_batch_gen_fibsq");
     if (b->single) {                                       // prover.rs:32-39 is serial: one trace gains nothing from the device
         b->single_trace.resize(b->n - 1);
         int rc = zk_trace_fibsq(a0[0], a1[0], b->n - 1, b->single_trace.data());
-        if (!rc) rc = zk_batch_set_traces(b, b->single_trace.data());
+        if (!rc) rc = set_traces_exclusive(b, b->single_trace.data());
         return rc;
     }
     HIPCHK(hipSetDevice(b->device));
