@@ -174,3 +174,18 @@ def test_config5_fieldhash_full_prover_domain_2e24(zk, field_oracle):
         sha_ctx.lde()
         assert hashlib.sha256(sha_ctx.layer_read(0).tobytes()).hexdigest() == f_digest
     assert N == 1 << 24
+
+
+@pytest.mark.gpu
+def test_fieldhash_device_forms_agree_on_random_and_edge_inputs(zk):
+    """Round 5: every tree is hashed in double precision on the device (csrc/fieldhash_f64.hpp), the host side keeps the 32-bit
+    Montgomery form and the narrow tree levels a 16-lane row form.  2^20 pseudo-random (inner, leaf) inputs per seed, every 16th an
+    edge pattern (words 0, P - 1, all P - 1, all 0, raw words >= P), through all three on the GPU: identical, canonical."""
+    import ctypes as C
+    from zkstark_amd import _lib
+    lib = _lib.load()
+    for seed in (1, 0x9E3779B9, 77):
+        bad, first = C.c_uint32(123), C.c_uint32(0)
+        _lib.check(lib.zk_probe_fieldhash_forms(0, 1 << 20, seed, C.byref(bad), C.byref(first)))
+        assert bad.value == 0, f"seed {seed}: {bad.value} inputs differ, the first at thread {first.value}"
+

@@ -85,6 +85,7 @@ SYMBOLS = {
     "zk_field_pow": (_u32, [_u32, _u32]),
     "zk_field_from_u32": (_u32, [_u32]),
     "zk_field_from_i32": (_u32, [C.c_int32]),
+    "zk_probe_fieldhash_forms": (_int, [_int, _u32, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "zk_field_div": (_u32, [_u32, _u32]),
     "zk_field_rem": (_u32, [_u32, _u32]),
     "zk_field_generator": (_u32, []),

@@ -1234,6 +1234,59 @@ hipError_t launch_hash_chain_probe(int hash, uint32_t blocks, uint32_t* out, uin
     return hipGetLastError();
 }
 
+// The three forms of the field hash on the device against each other (test hook: zk_probe_fieldhash_forms).  Thread t hashes a
+// pseudo-random pair of digests and a leaf value, every 16th thread one of the edge patterns (words 0, P - 1, all P - 1, all 0,
+// raw words >= P): double precision (what every tree is built with) and 32-bit Montgomery (the host's form) must agree word for
+// word and be canonical; the 16-lane row form of the narrow levels is compared on the first pair of each row.
+__global__ __launch_bounds__(256) void fieldhash_forms_kernel(uint32_t seed, uint32_t* bad, uint32_t* first_bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = (t + 1u) * 2654435761u + seed;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    Digest l, r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { l.w[i] = rnd() % P; r.w[i] = rnd() % P; }
+    if ((t & 15u) == 1) { l.w[t & 7u] = 0; r.w[(t >> 4) & 7u] = P - 1; }
+    if ((t & 15u) == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { l.w[i] = P - 1; r.w[i] = P - 1; }
+    }
+    if ((t & 15u) == 3) { l.w[0] = 0xFFFFFFFFu; r.w[7] = P; r.w[3] = P + 5; }                  // raw words >= P (field.rs:20-24)
+    if ((t & 15u) == 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { l.w[i] = 0; r.w[i] = 0; }
+    }
+    uint32_t v = rnd();
+    if ((t & 7u) == 0) v = (t & 8u) ? 0xFFFFFFFFu : P - 1;
+    if (t == 5) v = 0;
+    const Digest a = fieldhash_inner(l, r, g_fh_consts), b = fieldhash_inner64(l, r, g_fh_consts64);
+    const Digest c = fieldhash_leaf(v, g_fh_consts), d = fieldhash_leaf64(v, g_fh_consts64);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ok = ok && a.w[i] == b.w[i] && c.w[i] == d.w[i] && b.w[i] < P && d.w[i] < P;
+    // row form: the 16 lanes of a row hash the pair of the row's first thread
+    const uint32_t g = threadIdx.x & 15u;
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t lw = __shfl(l.w[i], (int)(threadIdx.x & ~15u) & 63, 64), rw = __shfl(r.w[i], (int)(threadIdx.x & ~15u) & 63, 64);
+        if (g == (uint32_t)i) word = lw;
+        if (g == (uint32_t)i + 8u) word = rw;
+    }
+    const uint32_t row = fieldhash_inner_row16(word, g, g_fh_consts);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t want = __shfl(b.w[i], (int)(threadIdx.x & ~15u) & 63, 64);
+        if (g == (uint32_t)i && row != want) ok = false;
+    }
+    if (!ok) { atomicAdd(bad, 1u); atomicMin(first_bad, t); }
+}
+hipError_t launch_fieldhash_forms(uint32_t blocks, uint32_t seed, uint32_t* d_res, hipStream_t s) {
+    hipError_t e = ensure_fieldhash_consts();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fieldhash_forms_kernel, dim3(blocks), dim3(256), 0, s, seed, d_res, d_res + 1);
+    return hipGetLastError();
+}
+
 // ===========================================================================
 // Trace generation for batches
 // ===========================================================================

@@ -243,6 +243,8 @@ hipError_t launch_trace_fibsq_batch(const uint32_t* a0, const uint32_t* a1, uint
 
 // measurement only: blocks x 256 lanes, each a chain of `hashes` inner hashes; rec (optional): per wave {shader clocks, 100 MHz ticks}
 hipError_t launch_hash_chain_probe(int hash, uint32_t blocks, uint32_t* out, uint32_t seed, uint32_t hashes, unsigned long long* rec, hipStream_t s);
+// d_res[0] <- number of threads whose hashes differ between the forms of the field hash, d_res[1] <- the first such thread (d_res preset to {0, ~0})
+hipError_t launch_fieldhash_forms(uint32_t blocks, uint32_t seed, uint32_t* d_res, hipStream_t s);
 
 // out[i*words .. ] = src[offsets[i] .. +words]   (decommit gather)
 hipError_t launch_gather(const uint32_t* src, const uint64_t* offsets, uint32_t count, uint32_t words,

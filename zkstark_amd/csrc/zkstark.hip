@@ -1489,6 +1489,25 @@ int zk_probe_hash_chain(int device, int hash_kind, uint32_t waves_per_simd, uint
     return rc;
 }
 
+// Test hook: the device's forms of the field hash against each other on `count` (rounded up to 256) pseudo-random and edge inputs.
+int zk_probe_fieldhash_forms(int device, uint32_t count, uint32_t seed, uint32_t* mismatches, uint32_t* first_bad) {
+    if (!mismatches || count == 0 || count > (1u << 26)) return fail(ZK_ERR_INVALID, "zk_probe_fieldhash_forms: bad argument");
+    HIPCHK(hipSetDevice(device));
+    uint32_t* d_res = nullptr;
+    HIPCHK(hipMalloc(&d_res, 8));
+    const uint32_t init[2] = {0u, 0xFFFFFFFFu};
+    int rc = ZK_OK;
+    uint32_t res[2] = {0, 0};
+    if (hipMemcpy(d_res, init, 8, hipMemcpyHostToDevice) != hipSuccess || launch_fieldhash_forms((count + 255) / 256, seed, d_res, nullptr) != hipSuccess ||
+        hipMemcpy(res, d_res, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(ZK_ERR_HIP, "zk_probe_fieldhash_forms: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d_res);
+    if (rc) return rc;
+    *mismatches = res[0];
+    if (first_bad) *first_bad = res[1];
+    return ZK_OK;
+}
+
 int zk_ntt_host(int device, uint32_t* data, uint32_t log_m, int inverse) {
     if (!data || log_m < 1 || log_m > 30) return fail(ZK_ERR_INVALID, "zk_ntt_host: bad argument");
     size_t m = (size_t)1 << log_m;
