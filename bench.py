@@ -341,10 +341,11 @@ class Watchdog:
             if late and on_late is not None:
                 print(f"[bench] rank {self.rank}: WATCHDOG: secondary leg '{what}' did not finish in time; the line is printed without it",
                       file=sys.stderr, flush=True)
+                code = 0
                 try:
-                    on_late(what)
+                    code = on_late(what) or 0             # e.g. 4 when the headline proof had already failed its parity check
                 finally:
-                    os._exit(0)
+                    os._exit(code)
             if late:
                 print(f"[bench] rank {self.rank}: WATCHDOG: '{what}' did not finish in time; this worker exits (7) and the supervisor "
                       f"starts a fresh one on the next rung", file=sys.stderr, flush=True)
@@ -914,6 +915,7 @@ def main():
                 result["legs_skipped"].append(f"{what}: did not finish within {LEG_BUDGET_S:.0f} s (watchdog); this leg and the later ones are missing")
                 if rank == 0:
                     emit_line(result)
+                return result.get("exit_code") or 0
             wd.arm(LEG_BUDGET_S, what, on_late=late)
 
         # parity: every rank's bytes must equal the single-GPU prover's
