@@ -27,6 +27,12 @@ const char* last_error() { return g_last_error.c_str(); }
 
 Plan make_plan(uint32_t log_m) {
     Plan p;
+    // (kernels.hpp: ZK_NTT_RADIX512, measured and off) 2^17 words in two passes of radix 512 x 256 instead of three
+    if (ZK_NTT_RADIX512 && log_m == 17) {
+        p.nd = 2;
+        p.bits[0] = 9; p.bits[1] = 8;
+        return p;
+    }
     uint32_t np = (log_m + kMaxRadixLog - 1) / kMaxRadixLog;
     if (np == 0) np = 1;
     uint32_t base = log_m / np, extra = log_m % np;
@@ -36,7 +42,7 @@ Plan make_plan(uint32_t log_m) {
 }
 
 uint32_t pick_logC(uint32_t log_total, uint32_t logR) {
-    uint32_t cols = log_total - logR, cap = ntt_tile_log(log_total) - logR;
+    uint32_t cols = log_total - logR, cap = ntt_pass_tile_log(log_total, logR) - logR;
     return cols < cap ? cols : cap;
 }
 
@@ -71,7 +77,7 @@ int run_dif(const uint32_t* src, uint32_t* data, uint32_t log_m, const Plan& pl,
         NttPassArgs a{};
         a.batch = batch; a.src_stride = d == 0 ? src_stride : data_stride; a.dst_stride = data_stride;
         a.src = d == 0 ? src : data; a.dst = data; a.log_total = log_m;
-        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR); a.tile_log = ntt_tile_log(log_m);
+        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR); a.tile_log = ntt_pass_tile_log(log_m, a.logR);
         a.L = L; a.tw = tw_inv; a.scale_mont = (inner == 0) ? scale_mont : 0;
         HIPCHK(launch_ntt_pass(a, NTT_DIF, s, prof));
     }
@@ -83,7 +89,7 @@ int run_dit(uint32_t* data, uint32_t log_m, const Plan& pl, PowTable tw, uint32_
     for (int d = (int)pl.nd - 1; d >= 0; --d) {
         NttPassArgs a{};
         a.src = data; a.dst = data; a.log_total = log_m;
-        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR); a.tile_log = ntt_tile_log(log_m);
+        a.logR = pl.bits[d]; a.logS = inner; a.logC = pick_logC(log_m, a.logR); a.tile_log = ntt_pass_tile_log(log_m, a.logR);
         a.L = L; a.tw = tw;
         HIPCHK(launch_ntt_pass(a, NTT_DIT, s));
         inner += pl.bits[d];
@@ -169,7 +175,7 @@ int dom_lde(const zk_dom* d, const uint32_t* d_trace, uint32_t* d_coef, uint32_t
     uint32_t inner = d->log_b;
     for (int q = (int)d->plan.nd - 1; q >= 0; --q) {
         NttPassArgs a{};
-        a.log_total = d->L; a.logR = d->plan.bits[q]; a.logS = inner; a.logC = pick_logC(d->L, a.logR); a.tile_log = ntt_tile_log(d->L);
+        a.log_total = d->L; a.logR = d->plan.bits[q]; a.logS = inner; a.logC = pick_logC(d->L, a.logR); a.tile_log = ntt_pass_tile_log(d->L, a.logR);
         a.L = d->L; a.tw = d->H.view();
         a.dst = d_out;
         a.batch = batch; a.dst_stride = os; a.src_stride = os;

@@ -1,9 +1,9 @@
-// ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256).
+// ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256; 512 as a build option, measured slower).
 //
 // Same pass semantics as ntt_pass_kernel (kernels.hip): the array is [A][R][S], a workgroup owns
 // C columns x R rows.  The tile is R*C = 4096 words, 2048 for transforms of up to 2^20 words
 // (NttPassArgs.tile_log; kernels.hpp: ntt_tile_log says why: many light workgroups per compute unit).
-// The R-point transform is a four-step inside the tile, R = Ra*Rb with Ra, Rb <= 16:
+// The R-point transform is a four-step inside the tile, R = Ra*Rb with Ra <= 16, Rb <= 32:
 //
 //   step 1  thread (tb, c): loads rows ta*Rb + tb, ta < Ra, straight into registers (lanes run
 //           along c: whole 128 B row segments), applies the inter-pass twiddle
@@ -44,13 +44,13 @@ constexpr uint32_t c_powmod(uint32_t a, uint64_t e) {
     return r;
 }
 constexpr uint32_t c_to_mont(uint32_t a) { return (uint32_t)((((uint64_t)a) << 32) % P); }
-constexpr uint32_t kW16 = c_powmod(GEN_W, (uint64_t)(P - 1) >> 4);          // primitive 16th root of unity
-constexpr uint32_t kW16Inv = c_powmod(kW16, 15);
+constexpr uint32_t kW32 = c_powmod(GEN_W, (uint64_t)(P - 1) >> 5);          // primitive 32nd root of unity
+constexpr uint32_t kW32Inv = c_powmod(kW32, 31);
 
-// w16^e (forward) or w16^-e (inverse) in Montgomery form, e < 8
+// w32^e (forward) or w32^-e (inverse) in Montgomery form, e < 16
 template <bool INV>
-struct Root16 {
-    static constexpr uint32_t w(int e) { return c_to_mont(c_powmod(INV ? kW16Inv : kW16, (uint64_t)e)); }
+struct Root32 {
+    static constexpr uint32_t w(int e) { return c_to_mont(c_powmod(INV ? kW32Inv : kW32, (uint64_t)e)); }
 };
 
 constexpr int c_brev(int x, int bits) {
@@ -71,11 +71,11 @@ __device__ __forceinline__ void dft_regs(uint32_t (&x)[1 << LOG]) {
             const int len = 1 << ll;
             const int j = b & (len - 1);
             const int i = ((b >> ll) << (ll + 1)) | j;
-            const int e = (j << (LOG - 1 - ll)) * (16 / R);      // exponent of w16
+            const int e = (j << (LOG - 1 - ll)) * (32 / R);      // exponent of w32
             uint32_t u = x[i], v = x[i + len];
             x[i] = add(u, v);
             uint32_t d = sub(u, v);
-            x[i + len] = (e == 0) ? d : mont_mul(d, Root16<INV>::w(e));
+            x[i + len] = (e == 0) ? d : mont_mul(d, Root32<INV>::w(e));
         }
     }
 }
@@ -381,6 +381,11 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
         case 6: return launch2<MODE, 3, 3>(a, staged, blocks, s);
         case 7: return launch2<MODE, 4, 3>(a, staged, blocks, s);
         case 8: return launch2<MODE, 4, 4>(a, staged, blocks, s);
+#if ZK_NTT_RADIX512
+        // radix 512 = 16 x 32 (round 5, measured slower and off: kernels.hpp).  4096-word tile only (8 columns: 32-byte row segments);
+        // every thread has one 16-point item in step 1, half of them a 32-point item in step 2
+        case 9: return launch3<MODE, 4, 5, (int)kMidTileLog>(a, staged, blocks, s);
+#endif
     }
     return hipErrorInvalidValue;
 }
@@ -390,8 +395,9 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
 // True when launch_ntt_pass_fast will take this pass (the planner asks before it fuses the coefficient
 // preparation into the first LDE pass, which only this kernel implements).
 bool ntt_fast_ok(const NttPassArgs& a, NttMode mode) {
-    if (a.logR < 5 || a.logR > 8) return false;
+    if (a.logR < 5 || a.logR > (ZK_NTT_RADIX512 ? 9u : 8u)) return false;
     if (a.tile_log != kSmallTileLog && a.tile_log != kMidTileLog) return false;
+    if (a.logR == 9 && a.tile_log != kMidTileLog) return false;
     const uint32_t logC = a.tile_log - a.logR;
     if (a.log_total < a.tile_log || a.logC != logC) return false;
     if (mode == NTT_DIT_LDE && !(a.logS < logC)) return false;
