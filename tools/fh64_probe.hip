@@ -1,7 +1,9 @@
 // fh64_probe.hip -- is the field hash faster in double precision?  (csrc/fieldhash_f64.hpp against csrc/fieldhash.hpp)
 //   1. equality: 2^20 random inner hashes and leaf hashes (edge words 0, P-1, raw words >= P included) through both forms;
 //   2. issue rates of the double-precision ops the new form is made of (v_fma_f64, v_add_f64, v_mul_f64, v_rndne_f64);
-//   3. the two compiled hashes in a dependent chain, 4 and 8 workgroups per CU, 10 launches back to back: ns per hash per SIMD.
+//   3. the two compiled hashes in a dependent chain, 1 .. 8 workgroups per CU, 10 launches back to back: ns per hash per SIMD
+//      (one workgroup per CU = one wave per SIMD: the latency of one hash on a lone wave);
+//   4. the two 16-lane row forms (narrow tree levels) in a dependent chain.
 // Build: hipcc -O3 --offload-arch=gfx950 -I zkstark_amd/csrc -o tools/fh64_probe tools/fh64_probe.hip zkstark_amd/csrc/host_sha.cpp
 #include <hip/hip_runtime.h>
 
@@ -53,6 +55,20 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t* out, uint32_t seed
 #pragma unroll
     for (int i = 0; i < 8; ++i) x ^= d.w[i];
     out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+
+// the 16-lane row forms in a dependent chain: lane g of a row holds word g of left || right; the digest comes back in lanes g < 8
+template <int F64>
+__global__ __launch_bounds__(256) void row_chain_kernel(uint32_t* out, uint32_t seed, int hashes) {
+    const uint32_t g = threadIdx.x & 15u;
+    uint32_t w = (seed * (g + 1) + (threadIdx.x >> 4) * 131u + blockIdx.x * 977u) % P;
+#pragma unroll 1
+    for (int it = 0; it < hashes; ++it) {
+        const uint32_t d = F64 ? fieldhash_inner_row16_f64(w, g, g_c64) : fieldhash_inner_row16(w, g, g_c32);
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x120 + 8, 0xF, 0xF, false);   // lanes 8..15 take lanes 0..7
+        w = g < 8 ? d : (up ^ 1u) % P;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = w;
 }
 
 constexpr int ITER = 128, UNROLL = 32, ACC = 8;
@@ -137,15 +153,28 @@ int main() {
             const double instr = (double)reps * wps * ITER * UNROLL * ACC;      // per SIMD (one wave of a block per SIMD)
             printf("%-12s %d waves/SIMD: %6.3f ns per instruction per SIMD (%.2f cycles at 2.4 GHz)\n", names[op], wps, ms * 1e6 / instr, ms * 1e6 / instr * 2.4);
         }
+    // (a form of the double-precision hash with the 16 S-boxes of a full round advancing in step, for lone waves, was measured
+    //  here in round 5: 10.52 against 10.61 us per hash at one wave per SIMD -- the compiler's schedule is not what limits it; removed)
+    const char* forms[2] = {"32-bit Montgomery", "double precision"};
     for (int f64 = 0; f64 < 2; ++f64)
-        for (int wps : {2, 4, 6, 8}) {
+        for (int wps : {1, 2, 4, 8}) {
             const int blocks = cus * wps, reps = 10, hashes = 8;
             double ms = time_ms([&](int r) {
                 if (f64) hipLaunchKernelGGL(chain_kernel<1>, dim3(blocks), dim3(256), 0, 0, d_out, 77u + r, hashes);
                 else hipLaunchKernelGGL(chain_kernel<0>, dim3(blocks), dim3(256), 0, 0, d_out, 77u + r, hashes);
             }, reps);
-            printf("inner hash chain, %-16s %d waves/SIMD launched: %8.2f ns per hash per SIMD\n", f64 ? "double precision" : "32-bit Montgomery", wps,
-                   ms * 1e6 / ((double)reps * wps * hashes));
+            printf("inner hash chain, %-18s %d waves/SIMD launched: %8.2f ns per hash per SIMD%s\n", forms[f64], wps,
+                   ms * 1e6 / ((double)reps * wps * hashes), wps == 1 ? "  (= the latency of one hash on a lone wave)" : "");
+        }
+    for (int f64 = 0; f64 < 2; ++f64)
+        for (int wps : {1, 2}) {
+            const int blocks = cus * wps, reps = 10, hashes = 16;
+            double ms = time_ms([&](int r) {
+                if (f64) hipLaunchKernelGGL(row_chain_kernel<1>, dim3(blocks), dim3(256), 0, 0, d_out, 99u + r, hashes);
+                else hipLaunchKernelGGL(row_chain_kernel<0>, dim3(blocks), dim3(256), 0, 0, d_out, 99u + r, hashes);
+            }, reps);
+            printf("16-lane row form, %-18s %d waves/SIMD launched: %8.2f ns per dependent hash\n", f64 ? "double precision" : "32-bit Montgomery", wps,
+                   ms * 1e6 / ((double)reps * hashes));
         }
     return 0;
 }

@@ -19,10 +19,9 @@
 //                             [-P/2, P/2] every second round, s_12 .. s_15 every round (fh64_internal); s_0 by its S-box
 //   Digest words are canonical residues again: reduce, add P if negative, convert.
 //
-// Used by the throughput kernel (merkle_subtree_kernel<.., HASH = 1>), the leaf / wide levels of the latency kernel and
-// the chain probe; the 16-lane row form of the narrow levels stays in 32-bit Montgomery arithmetic (fieldhash.hpp: it is
-// latency, not throughput, that counts there).  Device only; the host (verifier, tree tops of the sharded prover) keeps
-// the Montgomery code; the tests compare both with an independent plain-residue implementation.
+// Used by the throughput kernel (merkle_subtree_kernel<.., HASH = 1>), the leaf / wide levels of the latency kernel, the
+// chain probe, and -- as a 16-lane row form, at the end of this file -- the narrow levels.  Device only; the host (verifier, tree
+// tops of the sharded prover) keeps the Montgomery code; the tests compare both with an independent plain-residue implementation.
 #pragma once
 #include "fieldhash.hpp"
 
@@ -150,6 +149,60 @@ __device__ __forceinline__ Digest fieldhash_inner64(const Digest& l, const Diges
     Digest d;
     fh64_compress(in, d.w, c);
     return d;
+}
+
+// ---- one hash on a ROW of sixteen lanes, in double precision ------------------------------------------------------------
+// The narrow levels of a tree (fewer nodes than the workgroup has rows) cost one hash latency each.  fieldhash_inner_row16
+// (fieldhash.hpp) spreads the 32-bit permutation over a DPP row: ~1 700 instructions, 5.2 us per pass on a lone wave (64-bit
+// multiply-adds and their reductions, DPP hazards).  The same layout with the arithmetic of this file: lane g of a row holds
+// state element g as a signed double; the M4 block map is four quad broadcasts and a multiply-add chain with the lane's matrix
+// row, the block sum three row rotations, the internal layer's sum four rotate-and-add steps; every lane reduces its element in
+// every partial round (uniform code: the row form cannot skip per element).  ~1 170 instructions per hash.
+template <int CTRL>
+__device__ __forceinline__ double fh64_dpp(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+#else
+    return v;
+#endif
+}
+// E on a row: y = M4 * (own quad), then s = y + (sum of the four quads' y at the same position)
+__device__ __forceinline__ double fh64_external_row(double s, double c0, double c1, double c2, double c3) {
+    const double x0 = fh64_dpp<0x00>(s), x1 = fh64_dpp<0x55>(s), x2 = fh64_dpp<0xAA>(s), x3 = fh64_dpp<0xFF>(s);   // quad_perm broadcasts
+    const double y = __builtin_fma(c3, x3, __builtin_fma(c2, x2, __builtin_fma(c1, x1, c0 * x0)));
+    return (__builtin_fma(y, 2.0, fh64_dpp<kDppRowRor + 4>(y)) + fh64_dpp<kDppRowRor + 8>(y)) + fh64_dpp<kDppRowRor + 12>(y);
+}
+// in_word: word g of left || right (any u32), g = lane & 15; returns word g of the digest (canonical) in lanes g < 8.
+__device__ __forceinline__ uint32_t fieldhash_inner_row16_f64(uint32_t in_word, uint32_t g, const FieldHashConsts64& c) {
+    // row (g & 3) of M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
+    const uint32_t q = g & 3u;
+    const double c0 = q == 0 ? 5.0 : q == 1 ? 4.0 : 1.0;
+    const double c1 = q == 0 ? 7.0 : q == 1 ? 6.0 : q == 2 ? 3.0 : 1.0;
+    const double c2 = q < 2 ? 1.0 : q == 2 ? 5.0 : 4.0;
+    const double c3 = q == 0 ? 3.0 : q == 1 ? 1.0 : q == 2 ? 7.0 : 6.0;
+    const double dg = g == 0 ? -2.0 : (double)(1u << (g == 0 ? 0u : g - 1u));
+    double rcf[kFhRF];                                      // this lane's constants of the full rounds: read before they are needed
+#pragma unroll
+    for (int r = 0; r < kFhRF; ++r) rcf[r] = c.rc_full[r][g];
+    const double keep = (double)in_word;
+    double s = fh64_external_row(keep, c0, c1, c2, c3);
+#pragma unroll
+    for (int r = 0; r < kFhRF / 2; ++r) s = fh64_external_row(fh64_sbox(s + rcf[r]), c0, c1, c2, c3);
+#pragma unroll 1
+    for (int r = 0; r < kFhRP; ++r) {
+        const double t = fh64_sbox(s + c.rc_part[r]);
+        s = g == 0 ? t : s;
+        double sum = s + fh64_dpp<kDppRowRor + 8>(s);
+        sum = sum + fh64_dpp<kDppRowRor + 4>(sum);
+        sum = sum + fh64_dpp<kDppRowRor + 2>(sum);
+        sum = sum + fh64_dpp<kDppRowRor + 1>(sum);
+        s = fh64_reduce(__builtin_fma(s, dg, sum));         // d_g s + sum: <= 2^14 * 2^37.7 + 2^41.7 on the first round, 2^45 after
+    }
+#pragma unroll
+    for (int r = kFhRF / 2; r < kFhRF; ++r) s = fh64_external_row(fh64_sbox(s + rcf[r]), c0, c1, c2, c3);
+    return fh64_canonical(s + keep);
 }
 
 }  // namespace zk

@@ -687,6 +687,11 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
 // level `depth_in` (raw values in LEAF mode), keeps them in LDS and reduces them to ONE node with
 // workgroup barriers only; a launch therefore lowers the tree by j levels.
 constexpr int kWgThreads = 256;
+#ifndef ZK_FIELD_ROW_MAX_NODES
+#define ZK_FIELD_ROW_MAX_NODES 32
+#endif
+constexpr uint32_t kFieldRowMaxNodes = ZK_FIELD_ROW_MAX_NODES;   // levels of <= this many nodes per workgroup use the 16-lane row form of the field hash
+static_assert(kFieldRowMaxNodes >= 16 && kFieldRowMaxNodes <= 64, "the row form takes at most four passes of 16 nodes");
 constexpr uint32_t kWgMaxLog = 10;   // 1024 digests = 32 KiB LDS per workgroup
 
 __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
@@ -828,10 +833,12 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
             __syncthreads();
             continue;
         }
-        if (HASH == 1 && w <= 64) {
-            // Latency-bound level of the field hash: one hash per ROW of 16 lanes (fieldhash_inner_row16: the 16 state
-            // elements on 16 lanes, ~1 700 instructions instead of ~9 000 on one lane), 16 hashes per pass of the
-            // workgroup.  Every lane runs the permutation (DPP needs whole rows); only real nodes are stored.
+        if (HASH == 1 && w <= kFieldRowMaxNodes) {
+            // Narrow level of the field hash: one hash per ROW of 16 lanes in double precision (fieldhash_inner_row16_f64: the 16
+            // state elements on 16 lanes, quad broadcasts and row rotations, ~1 170 instructions), 16 hashes per pass of the
+            // workgroup, 3.9 us per pass (the 32-bit row form of rounds 3-4: 5.4); the one-lane hash takes ~11 us for up to 256
+            // nodes, so the row form pays up to 32 nodes per workgroup (profiles/r05_ab_field_row.txt: 16 / 32 / 64 swept).
+            // Every lane runs the permutation (DPP needs whole rows).
             const uint32_t g = tid & 15u, grp = tid >> 4;
             uint32_t res[4];
 #pragma unroll
@@ -839,7 +846,7 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
                 if (b * 16 >= w) break;                                // workgroup-uniform
                 const uint32_t node = b * 16 + grp;
                 const uint32_t* words = reinterpret_cast<const uint32_t*>(&lvl[4 * (node < w ? node : 0u)]);   // children 2 node, 2 node + 1
-                res[b] = fieldhash_inner_row16(words[g], g, g_fh_consts);
+                res[b] = fieldhash_inner_row16_f64(words[g], g, g_fh_consts64);
             }
             __syncthreads();                                       // every read of the level done
 #pragma unroll
@@ -989,16 +996,16 @@ bool set_merkle_latency_log(uint32_t v) {
 // ---- how the latency phase of a tree is cut into (phase 1, continuation) -------------------------------------------
 // Microseconds one workgroup, alone on its compute unit, needs for a level of w nodes (every form costs one hash LATENCY per
 // pass: measured per form): SHA-256 one lane per hash 4.6 (256 per pass), main / helper lanes 4.9 (128),
-// four lanes per hash 3.1 (64); field hash one lane per hash in double precision ~20 (256 per pass), a row of 16 lanes 4.5 (16)
-// (from the kernel trace of a field-hash proof, profiles/r05_ab_continuation.txt).
+// four lanes per hash 3.1 (64); field hash one lane per hash in double precision ~11 (256 per pass; tools/fh64_probe.hip: 10.7 us
+// on a lone wave), a row of 16 lanes in double precision 3.9 (16 per pass; the 32-bit row form of rounds 3-4: 5.4).
 static double wg_level_us(uint32_t w, int hash) {
     if (w == 0) return 0.0;
-    if (hash) return w <= 64 ? (double)((w + 15) / 16) * 4.5 : (double)((w + 255) / 256) * 20.0;
+    if (hash) return w <= kFieldRowMaxNodes ? (double)((w + 15) / 16) * 3.9 : (double)((w + 255) / 256) * 11.0;
     return w <= 64 ? 3.1 : w <= 128 ? 4.9 : (double)((w + 255) / 256) * 4.6;
 }
 static double wg_phase_us(bool leaf, uint32_t cnt_log, uint32_t levels, int hash, uint32_t blocks) {
     const uint32_t cnt = 1u << cnt_log;
-    double us = leaf ? (double)((cnt + 255) / 256) * (hash ? 20.0 : 2.6) : 1.0;   // leaf hashes, or the first load
+    double us = leaf ? (double)((cnt + 255) / 256) * (hash ? 11.0 : 2.6) : 1.0;   // leaf hashes, or the first load
     for (uint32_t t = 1; t <= levels; ++t) us += wg_level_us(cnt >> t, hash);
     return blocks > 256 ? us * (double)blocks / 256.0 : us;                        // more workgroups than compute units take turns
 }
@@ -1272,11 +1279,11 @@ __global__ __launch_bounds__(256) void fieldhash_forms_kernel(uint32_t seed, uin
         if (g == (uint32_t)i) word = lw;
         if (g == (uint32_t)i + 8u) word = rw;
     }
-    const uint32_t row = fieldhash_inner_row16(word, g, g_fh_consts);
+    const uint32_t row = fieldhash_inner_row16(word, g, g_fh_consts), row64 = fieldhash_inner_row16_f64(word, g, g_fh_consts64);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t want = __shfl(b.w[i], (int)(threadIdx.x & ~15u) & 63, 64);
-        if (g == (uint32_t)i && row != want) ok = false;
+        if (g == (uint32_t)i && (row != want || row64 != want)) ok = false;
     }
     if (!ok) { atomicAdd(bad, 1u); atomicMin(first_bad, t); }
 }
