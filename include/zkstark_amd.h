@@ -445,9 +445,9 @@ typedef struct zk_chain_probe {
 } zk_chain_probe;
 int zk_probe_hash_chain(int device, int hash_kind, uint32_t waves_per_simd, uint32_t hashes, uint32_t launches, zk_chain_probe *out);
 
-/* Test hook (configs[4]): the field hash exists in three forms on the device -- double precision (every tree is built with it,
- * csrc/fieldhash_f64.hpp), 32-bit Montgomery (the host's form: verifier, tree tops of the sharded prover) and the 16-lane row form
- * of the narrow tree levels.  Hashes `count` pseudo-random inputs, every 16th an edge pattern (words 0, P - 1, raw words >= P), through
+/* Test hook (configs[4]): the field hash exists in several forms on the device -- double precision one lane per node (every tree is
+ * built with it, csrc/fieldhash_f64.hpp), its quad and 16-lane row forms (the narrow tree levels), 32-bit Montgomery (the host's form:
+ * verifier, tree tops of the sharded prover) and the 32-bit row form of rounds 3-4.  Hashes `count` pseudo-random inputs, every 16th an edge pattern (words 0, P - 1, raw words >= P), through
  * all of them: *mismatches = inputs on which they differ or a digest word is not canonical (must be 0). */
 int zk_probe_fieldhash_forms(int device, uint32_t count, uint32_t seed, uint32_t *mismatches, uint32_t *first_bad);
 

@@ -205,5 +205,57 @@ __device__ __forceinline__ uint32_t fieldhash_inner_row16_f64(uint32_t in_word, 
     return fh64_canonical(s + keep);
 }
 
+// ---- one hash on a QUAD of four lanes, in double precision ----------------------------------------------------------------
+// Between the one-lane hash (10.6 us on a lone wave, 256 nodes per workgroup and pass) and the 16-lane row form (3.9 us, 16
+// nodes per pass): lane q of a quad holds 4-block q of the state.  The M4 block map is local (8 instructions), the block sums and
+// the internal layer's sum are two quad exchanges per value (quad_perm [1,0,3,2] and [2,3,0,1]), the S-boxes of a full round run
+// four per lane.  ~1 950 instructions per hash, ~6 us on a lone wave, 64 nodes per pass: levels of 33 .. 64 nodes per workgroup.
+__device__ __forceinline__ double fh64_quad_sum(double v) {
+    v = v + fh64_dpp<0xB1>(v);                             // quad_perm [1,0,3,2]
+    return v + fh64_dpp<0x4E>(v);                          // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void fh64_external_quad(double (&x)[4]) {
+    fh64_m4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = x[j] + fh64_quad_sum(x[j]);
+}
+// in_words: words 4q .. 4q+3 of left || right (any u32), q = lane & 3; lanes q < 2 return words 4q .. 4q+3 of the digest (canonical)
+__device__ __forceinline__ void fieldhash_inner_quad_f64(const uint32_t (&in_words)[4], uint32_t q, uint32_t (&out_words)[4], const FieldHashConsts64& c) {
+    double rcf[kFhRF][4];                                   // this lane's constants of the full rounds, all read up front
+#pragma unroll
+    for (int r = 0; r < kFhRF; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rcf[r][j] = c.rc_full[r][4 * q + j];
+    double dg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dg[j] = (q == 0 && j == 0) ? -2.0 : (double)(1u << ((4 * q + j) == 0 ? 0u : 4 * q + j - 1u));
+    double x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = (double)in_words[j];
+    fh64_external_quad(x);
+#pragma unroll
+    for (int r = 0; r < kFhRF / 2; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fh64_sbox(x[j] + rcf[r][j]);
+        fh64_external_quad(x);
+    }
+#pragma unroll 1
+    for (int r = 0; r < kFhRP; ++r) {
+        const double t = fh64_sbox(x[0] + c.rc_part[r]);
+        x[0] = q == 0 ? t : x[0];
+        const double sum = fh64_quad_sum((x[0] + x[1]) + (x[2] + x[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fh64_reduce(__builtin_fma(x[j], dg[j], sum));
+    }
+#pragma unroll
+    for (int r = kFhRF / 2; r < kFhRF; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fh64_sbox(x[j] + rcf[r][j]);
+        fh64_external_quad(x);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out_words[j] = fh64_canonical(x[j] + (double)in_words[j]);
+}
+
 }  // namespace zk
 #endif

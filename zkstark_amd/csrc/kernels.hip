@@ -692,6 +692,11 @@ constexpr int kWgThreads = 256;
 #endif
 constexpr uint32_t kFieldRowMaxNodes = ZK_FIELD_ROW_MAX_NODES;   // levels of <= this many nodes per workgroup use the 16-lane row form of the field hash
 static_assert(kFieldRowMaxNodes >= 16 && kFieldRowMaxNodes <= 64, "the row form takes at most four passes of 16 nodes");
+#ifndef ZK_FIELD_QUAD_MAX_NODES
+#define ZK_FIELD_QUAD_MAX_NODES 64      // profiles/r05_ab_field_quad.txt: 0 / 64 / 128 swept; a quad pass is ~6 us, so two of them lose to the one-lane hash
+#endif
+constexpr uint32_t kFieldQuadMaxNodes = ZK_FIELD_QUAD_MAX_NODES;   // ... of <= this many (and more than the row form's) one hash per quad of lanes; 0: never
+static_assert(kFieldQuadMaxNodes <= 128, "the quad form takes at most two passes of 64 nodes");
 constexpr uint32_t kWgMaxLog = 10;   // 1024 digests = 32 KiB LDS per workgroup
 
 __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
@@ -830,6 +835,34 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
             }
             __syncthreads();                                       // every read of lvl and xch done
             if (active && is_main) { lds_store(&lvl[2 * node], d0); store_digest(nodes, out_base + node, d0); }
+            __syncthreads();
+            continue;
+        }
+        if (HASH == 1 && w > kFieldRowMaxNodes && w <= kFieldQuadMaxNodes) {
+            // Level of 33 .. 64 nodes per workgroup of the field hash: one hash per QUAD of lanes (fieldhash_inner_quad_f64: a
+            // 4-block of the state per lane, ~1 950 instructions, ~6 us), 64 hashes per pass of the workgroup.  Lane q reads children
+            // words 4q .. 4q+3 as one 16-byte LDS access; lanes 0 and 1 of a quad hold the digest.
+            const uint32_t q = tid & 3u, grp = tid >> 2;
+            uint32_t res[2][4];
+#pragma unroll
+            for (uint32_t b = 0; b < 2; ++b) {
+                if (b * 64 >= w) break;                                // workgroup-uniform
+                const uint32_t node = b * 64 + grp;
+                const uint4 v = lvl[4 * (node < w ? node : 0u) + q];
+                const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+                fieldhash_inner_quad_f64(in, q, res[b], g_fh_consts64);
+            }
+            __syncthreads();                                       // every read of the level done
+#pragma unroll
+            for (uint32_t b = 0; b < 2; ++b) {
+                if (b * 64 >= w) break;
+                const uint32_t node = b * 64 + grp;
+                if (node < w && q < 2) {
+                    const uint4 o = make_uint4(res[b][0], res[b][1], res[b][2], res[b][3]);
+                    lvl[2 * node + q] = o;
+                    reinterpret_cast<uint4*>(nodes + (out_base + node) * 8)[q] = o;
+                }
+            }
             __syncthreads();
             continue;
         }
@@ -1000,7 +1033,7 @@ bool set_merkle_latency_log(uint32_t v) {
 // on a lone wave), a row of 16 lanes in double precision 3.9 (16 per pass; the 32-bit row form of rounds 3-4: 5.4).
 static double wg_level_us(uint32_t w, int hash) {
     if (w == 0) return 0.0;
-    if (hash) return w <= kFieldRowMaxNodes ? (double)((w + 15) / 16) * 3.9 : (double)((w + 255) / 256) * 11.0;
+    if (hash) return w <= kFieldRowMaxNodes ? (double)((w + 15) / 16) * 3.9 : w <= kFieldQuadMaxNodes ? (double)((w + 63) / 64) * 6.0 : (double)((w + 255) / 256) * 11.0;
     return w <= 64 ? 3.1 : w <= 128 ? 4.9 : (double)((w + 255) / 256) * 4.6;
 }
 static double wg_phase_us(bool leaf, uint32_t cnt_log, uint32_t levels, int hash, uint32_t blocks) {
@@ -1278,6 +1311,28 @@ __global__ __launch_bounds__(256) void fieldhash_forms_kernel(uint32_t seed, uin
         const uint32_t lw = __shfl(l.w[i], (int)(threadIdx.x & ~15u) & 63, 64), rw = __shfl(r.w[i], (int)(threadIdx.x & ~15u) & 63, 64);
         if (g == (uint32_t)i) word = lw;
         if (g == (uint32_t)i + 8u) word = rw;
+    }
+    {   // quad form: the 4 lanes of a quad hash the pair of the quad's first thread
+        const uint32_t q4 = threadIdx.x & 3u;
+        const int src = (int)(threadIdx.x & ~3u) & 63;
+        uint32_t in4[4], out4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t wsel = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t lw = __shfl(l.w[i], src, 64), rw = __shfl(r.w[i], src, 64);
+                if ((int)(4 * q4) + j == i) wsel = lw;
+                if ((int)(4 * q4) + j == i + 8) wsel = rw;
+            }
+            in4[j] = wsel;
+        }
+        fieldhash_inner_quad_f64(in4, q4, out4, g_fh_consts64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t want = __shfl(b.w[i], src, 64);
+            if (q4 < 2 && (int)(4 * q4) <= i && i < (int)(4 * q4) + 4 && out4[i - 4 * (int)q4 < 0 ? 0 : (i - 4 * (int)q4) & 3] != want) ok = false;
+        }
     }
     const uint32_t row = fieldhash_inner_row16(word, g, g_fh_consts), row64 = fieldhash_inner_row16_f64(word, g, g_fh_consts64);
 #pragma unroll
