@@ -360,6 +360,24 @@ def test_shard_ranks_as_threads_of_one_process(threads_check, orc, world, log_n,
     assert "board 1" in out.stdout
 
 
+@pytest.mark.parametrize("world,log_n,log_b,thresholds", [
+    (8, 14, 3, (1, 5, 8)),        # chunked exchanges on three streams, nothing waits on the host
+    (4, 20, 3, (0, 0, 0)),        # production thresholds at 2^21 elements per rank
+])
+def test_shard_ranks_as_threads_with_a_stream_ordered_transport(threads_check, orc, world, log_n, log_b, thresholds):
+    """The same harness with a transport that behaves like RCCL (ZK_HARNESS_ASYNC=1): no device synchronisation, peers' pieces
+    ordered by HIP events only.  The host-synchronous transports of the other multi-rank tests would hide a missing stream
+    dependency inside the library (a chunk hashed before it arrived, a receive buffer reused too early); this one would not."""
+    import subprocess
+    env = dict(os.environ, ZK_HARNESS_ASYNC="1")
+    out = subprocess.run([threads_check, str(world), str(log_n), str(log_b)] + [str(t) for t in thresholds] + ["2"],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = orc.prove(log_n, log_b, want_vectors=False)
+    assert f"threads ok: world {world}, {len(want.proof)} proof bytes on every rank equal zk_prove" in out.stdout
+    assert "[stream-ordered transport]" in out.stdout
+
+
 def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
     """The exact configuration `bench.py --gpus 8` proves: domain 2^27, eight ranks of 2^24 elements each, production
     thresholds (0 = defaults) -- here as eight threads on one GPU.  Every rank's bytes equal the single-GPU prover's at
