@@ -862,7 +862,7 @@ def main():
             dist.all_gather_object(gathered_, p_.data[:64] + p_.state)
             return {"proof": p_, "dt": float(t_.item()), "steps": steps_, "dom": dom_, "per_kernel": per_kernel_, "st": st_, "per_rank": per_rank_,
                     "plan": {k: plan_[k] for k in ("sharded_layers", "tail_rounds", "chunked_layers", "chunked_mask", "log_chunks", "overlap_min_log",
-                                                   "min_layer_log", "min_chunk_log", "piece_log", "all_to_all_bytes")},
+                                                   "min_layer_log", "min_chunk_log", "piece_log", "all_to_all_bytes", "cp_from_f")},
                     "chunked_mask": plan_["chunked_mask"], "ranks_agree": all(g == gathered_[0] for g in gathered_)}
 
         def shard_record(m_, n_elems):

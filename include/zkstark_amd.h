@@ -326,7 +326,9 @@ typedef struct zk_shard_options {   /* zero = default */
     int single_build_stream;    /* chunk builds of a layer on one stream (A/B; default: two alternating streams) */
     int single_communicator;    /* built-in RCCL transport: the exchange stream shares the main communicator (default: the
                                    chunked exchanges get a communicator of their own, see below) */
-    int reserved;
+    int exchange_cp;            /* 1: commit cp by exchanging it like every other layer (what rounds 1-4 did; A/B).  Default:
+                                   cp over a rank's block is recomputed from the block of f the rank received for the
+                                   commitment of f, inside the leaf hashing -- no exchange for cp (zk_shard_plan_info.cp_from_f) */
     double timeout_s;           /* bound of every host-side wait on a peer; 0 = environment ZK_SHARD_TIMEOUT_S, else 120 s */
 } zk_shard_options;
 typedef struct zk_shard_stats {
@@ -371,6 +373,10 @@ typedef struct zk_shard_plan_info {
     uint32_t piece_log[32];      /* log2 words of one (rank, peer) piece of layer id */
     double all_to_all_bytes;     /* bytes one rank sends to its peers in the all-to-alls of one proof */
     double lde_commit_bytes;     /* ... of zk_shard_lde_commit (layer 0 only) */
+    uint32_t cp_from_f;          /* 1: cp (layer id 1) is committed without an exchange: recomputed over the rank's block from the
+                                    received block of f plus a 2B-word all-gather (the positions after the block); its piece
+                                    is then not part of all_to_all_bytes */
+    uint32_t reserved;
 } zk_shard_plan_info;
 int zk_shard_plan(int world, uint32_t log_n, uint32_t log_blowup, const zk_shard_options *opt, zk_shard_plan_info *out);
 /* Streams and communicators.  Plain exchanges run on the prover's main stream.  Chunked exchanges (pieces of >=

@@ -166,6 +166,7 @@ int main(int argc, char **argv) {
         args[r].rank = r; args[r].log_n = log_n; args[r].log_b = log_b; args[r].id = id; args[r].trace = trace;
         args[r].opt.min_layer_log = (uint32_t)atoi(argv[4]); args[r].opt.min_chunk_log = (uint32_t)atoi(argv[5]);
         args[r].opt.overlap_min_log = (uint32_t)atoi(argv[6]);
+        args[r].opt.exchange_cp = getenv("ZK_HARNESS_EXCHANGE_CP") ? 1 : 0;   /* A/B: cp exchanged like every other layer (rounds 1-4) */
         args[r].cap = cap; args[r].proof = malloc(cap);
         args[r].reps = argc > 7 ? atoi(argv[7]) : 0;
         pthread_create(&th[r], NULL, run_rank, &args[r]);

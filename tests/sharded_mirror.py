@@ -400,9 +400,13 @@ class ShardedProver:
         # is the one statement of the layout, shared with the native prover (in zk_shard_options 0 selects the default, so the
         # smallest explicit threshold is 1: pieces of two leaves).
         from zkstark_amd.host import shard_plan
+        # cp without an exchange (zk_shard_plan_info.cp_from_f) needs the block form of the composition from the backend
+        # (OracleBackend.compose_block; the device form is internal to the library): other backends exchange cp as rounds 1-4 did
         plan = shard_plan(G, log_n, log_blowup, min_layer_log=0 if default_layout else max(min_layer_log, 1), min_chunk_log=max(min_chunk_log, 1),
-                          overlap_min_log=overlap_min_log, force_collectives=bool(getattr(comm, "force", False)))
+                          overlap_min_log=overlap_min_log, force_collectives=bool(getattr(comm, "force", False)),
+                          exchange_cp=not hasattr(backend, "compose_block"))
         self.plan = plan
+        self.cp_from_f = bool(plan["cp_from_f"])
         self.n_sharded = plan["sharded_layers"]
         self.chunked_mask = plan["chunked_mask"]
         h = root_of_unity(self.L)
@@ -415,7 +419,7 @@ class ShardedProver:
         self.tail = None
         if hasattr(be, "tail_create") and self.tail_rounds >= 1:
             self.tail = be.tail_create(self.tail_rounds, log_blowup, _pow(GEN_W, 1 << self.n_sharded))
-        self.dom_glob = be.domain(log_n, log_blowup, GEN_W, fold_only=True) if self.n_sharded <= self.R and self.tail is None else None
+        self.dom_glob = be.domain(log_n, log_blowup, GEN_W, fold_only=True) if (self.n_sharded <= self.R and self.tail is None) or self.cp_from_f else None
         # one allocation for layers, one for trees (as the single-GPU context)
         NL = self.N // G
         self.layer_off, self.layer_len, off = [], [], 0
@@ -535,6 +539,11 @@ class ShardedProver:
         else:
             be.merkle(loc, m_log - lg, nodes)
             mine = None
+        return self._join_subtrees(lid, nodes, mine)
+
+    def _join_subtrees(self, lid, nodes, mine):
+        """The G subtree roots on the host of every rank (shared page or all-gather), the top log2 G levels hashed by every rank."""
+        be, G = self.be, self.G
         if G > 1 or self.comm.force:
             if self.board is not None:
                 if mine is None:
@@ -549,6 +558,41 @@ class ShardedProver:
         top = host_merkle_top(subroots)
         self.tops[lid] = top
         return top[0]
+
+    # ---- cp without an exchange (csrc/shard.hip: commit_cp_from_f) -------------------------------------------
+    def _halo_pack(self):
+        """What the neighbour of every block needs of this rank's cyclic shard of f: the values at the first 2B positions
+        after block q are i = (q + 1) M + v, v < 2B; this rank holds those with v = r (mod G)."""
+        G, M = self.G, self.N // self.G
+        per, h = M // G, 2 * self.B // G
+        loc = self.be.to_host(self._layer(0))
+        send = np.array([loc[((q + 1) * per + u) % M] for q in range(G) for u in range(h)], dtype=np.uint32)
+        return self.be.upload(send)
+
+    def _block_of_f(self):
+        """This rank's block of f in natural order, from the receive buffer the commitment of f left behind (all-to-all order,
+        in chunks when the layer was exchanged in chunks)."""
+        be, G, lg = self.be, self.G, self.lg
+        M = self.N // G
+        recv = be.to_host(self.recv[:M])
+        if (G > 1 or self.comm.force) and hasattr(be, "merkle_chunk") and self.chunked_mask & 1:
+            K = 1 << self.log_chunks
+            return recv.reshape(K, G, M // (K * G)).transpose(0, 2, 1).reshape(-1)     # chunk c: leaf u G + q = recv[c][q][u]
+        return recv.reshape(G, M // G).T.reshape(-1)
+
+    def _commit_cp_from_f(self, halo_send, alphas):
+        be, G, lg, B = self.be, self.G, self.lg, self.B
+        M, h = self.N // G, 2 * self.B // G
+        gath = be.empty(2 * B * G)
+        self.comm.all_gather(halo_send, gath)
+        gath = be.to_host(gath)
+        halo = np.array([gath[(v % G) * 2 * B + self.rank * h + v // G] for v in range(2 * B)], dtype=np.uint32)
+        fext = np.concatenate([self._block_of_f(), halo])
+        cp_blk = be.empty(M)
+        be.compose_block(self.dom_glob, fext, self.rank * M, cp_blk, self.first, self.last, alphas)
+        nodes = self._tree(1)
+        be.merkle(cp_blk, self.L - lg, nodes)
+        return self._join_subtrees(1, nodes, None)
 
     def _commit_replicated(self, lid, m_log):
         nodes = self._tree(lid)
@@ -573,10 +617,15 @@ class ShardedProver:
         self.tops = {}
         roots = []
         be.lde(self.dom_loc, self.trace, self.coef, self._layer(0))                 # prover.rs:60-70
+        halo_send = self._halo_pack() if self.cp_from_f else None
         roots.append(self._commit_sharded(0, L)); ch.commit(roots[-1])              # prover.rs:81-85
         alphas = [ch.get_u32() for _ in range(3)]                                   # prover.rs:163-165
-        be.compose(self.dom_loc, self._layer(0), self._layer(1), self.first, self.last, alphas)   # :166-173
-        roots.append(self._commit_sharded(1, L)); ch.commit(roots[-1])              # prover.rs:176-180
+        be.compose(self.dom_loc, self._layer(0), self._layer(1), self.first, self.last, alphas)   # :166-173 (cyclic: the folds' input)
+        if self.cp_from_f:                                                          # over the block, from the received block of f
+            roots.append(self._commit_cp_from_f(halo_send, alphas))
+        else:
+            roots.append(self._commit_sharded(1, L))
+        ch.commit(roots[-1])                                                        # prover.rs:176-180
         betas = []
         for rho in range(R):                                                        # prover.rs:198-225
             beta = ch.get_u32(); betas.append(beta)

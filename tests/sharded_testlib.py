@@ -69,6 +69,28 @@ class OracleBackend:
             out[i] = (a0 * p0 + a1 * p1 + a2 * num * inv(den)) % P
             x = x * h % P
 
+    def compose_block(self, dom, fext, e0, out, first, last, alphas):
+        """cp at the positions e0 .. e0 + M - 1 of the GLOBAL domain `dom` (prover.rs:101-166 pointwise), from f at those
+        positions and the 2B after them (`fext`: M + 2B values in natural order).  What ComposeBlockSrc computes on the device."""
+        self.calls["compose_block"] = self.calls.get("compose_block", 0) + 1
+        n, B = 1 << dom["log_n"], 1 << dom["log_b"]
+        g, h, s = dom["g"], dom["h"], dom["shift"]
+        fv = [int(v) for v in np.asarray(fext, dtype=np.uint32)]
+        M = len(fv) - 2 * B
+        a0, a1, a2 = [int(a) % P for a in alphas]
+        inv = lambda v: pow(v, P - 2, P)
+        gm1 = inv(g); gm2 = gm1 * gm1 % P; gm3 = gm2 * gm1 % P
+        res = self._np(out)
+        x = s * pow(h, e0, P) % P
+        for t in range(M):
+            f0, f1, f2 = fv[t], fv[t + B], fv[t + 2 * B]
+            p0 = (f0 - first) * inv((x - 1) % P) % P
+            p1 = (f0 - last) * inv((x - gm2) % P) % P
+            num = (f2 - f1 * f1 - f0 * f0) % P
+            den = (pow(x, n, P) - 1) * inv((x - gm3) * (x - gm2) * (x - gm1) % P) % P
+            res[t] = (a0 * p0 + a1 * p1 + a2 * num * inv(den)) % P
+            x = x * h % P
+
     def fold(self, dom, src, dst, log_m, rnd, beta):
         self.calls["fold"] += 1
         assert log_m + rnd == dom["L"]

@@ -250,13 +250,18 @@ def test_shard_plan_is_the_one_layout(zk):
     The benchmark's weak-scaling configurations, the byte formula of DESIGN.md section 6, and the mirror's view of it."""
     # bench.py --gpus 2 / 4 / 8 (2^24 elements per GPU, production thresholds): GPU tests assert the same numbers on the prover's stats
     # (round 5: layers of >= 2^21 values stay distributed, >= 2^20 from 4 ranks on; the last rows are the strong shape of bench.py)
-    for world, log_n, want_sharded, want_chunked in ((2, 22, 5, 4), (4, 23, 7, 3), (8, 24, 8, 2), (8, 21, 5, 0), (4, 21, 5, 0), (2, 21, 4, 3), (1, 21, 4, 0)):
+    for world, log_n, want_sharded, want_chunked in ((2, 22, 5, 3), (4, 23, 7, 2), (8, 24, 8, 1), (8, 21, 5, 0), (4, 21, 5, 0), (2, 21, 4, 2), (1, 21, 4, 0)):
         pl = zk.shard_plan(world, log_n, 3)
         assert (pl["sharded_layers"], pl["chunked_layers"]) == (want_sharded, want_chunked), (world, log_n, pl)
         assert pl["tail_rounds"] == log_n - want_sharded and pl["log_chunks"] == 2
         N = 1 << (log_n + 3)
-        words = N + sum(N >> rho for rho in range(want_sharded))          # f and FRI layers 0 .. ns-1: one all-to-all each
+        words = N + sum(N >> rho for rho in range(1, want_sharded))       # f and FRI layers 1 .. ns-1: one all-to-all each; cp (FRI
+        assert pl["cp_from_f"] == (1 if world > 1 else 0)                 # layer 0) over a rank's block comes from the block of f it received
+        if world == 1:
+            words = 0
         assert pl["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world
+        old = zk.shard_plan(world, log_n, 3, exchange_cp=True)            # rounds 1-4: cp exchanged as well, 12 N instead of 8 N
+        assert old["cp_from_f"] == 0 and old["all_to_all_bytes"] == 4.0 * (N + sum(N >> rho for rho in range(want_sharded))) / world * (world - 1) / world
         assert pl["lde_commit_bytes"] == 4.0 * N / world * (world - 1) / world
         assert pl["piece_log"][0] == log_n + 3 - 2 * pl["log_world"]
     # explicit thresholds; at least one round stays in the replicated tail; a chunked layer needs pieces of >= 2^10 words

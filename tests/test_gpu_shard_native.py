@@ -248,10 +248,13 @@ def test_shard_failure_of_one_rank_is_contained(threads_check):
     (2, 16, 3, dict(min_layer_log=1, min_chunk_log=6, overlap_min_log=10)),          # chunked exchange, 2 ranks
     (4, 16, 2, dict(min_layer_log=10, min_chunk_log=6, overlap_min_log=10)),         # world = blow-up: local blow-up 1
     (2, 14, 3, dict(min_layer_log=1, min_chunk_log=6, no_root_board=True)),          # roots by all-gather
+    (2, 16, 3, dict(min_layer_log=1, min_chunk_log=6, overlap_min_log=10, exchange_cp=True)),   # cp exchanged like every other layer (rounds 1-4)
+    (4, 14, 3, dict(min_layer_log=1, min_chunk_log=6, exchange_cp=True)),
 ])
 def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
     """Every rank's proof, state and all R + 2 roots equal the CPU oracle's; the exchanged volume is what
-    DESIGN.md section 6 states: 4 bytes per element per distributed layer, a share (G-1)/G of it to peers."""
+    DESIGN.md section 6 states: 4 bytes per element per EXCHANGED layer -- f and every distributed FRI layer but cp, which is
+    recomputed over the rank's block from the received block of f (exchange_cp: cp too) --, a share (G-1)/G of it to peers."""
     want = orc.prove(log_n, log_b, want_vectors=False, want_roots=True)
     out = _run(world, log_n, log_b, opts, "prove")
     N = 1 << (log_n + log_b)
@@ -260,20 +263,26 @@ def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
         ns = st["sharded_layers"]
         assert ns >= 2 and st["root_board"] == (0 if opts.get("no_root_board") else 1) and st["native_rccl"] == 0
-        words = N + sum(N >> rho for rho in range(ns))              # f and FRI layers 0 .. ns-1, one all-to-all each
+        words = N + sum(N >> rho for rho in range(ns))              # f and FRI layers 0 .. ns-1, one all-to-all each ...
+        if not opts.get("exchange_cp"):
+            words -= N                                                # ... but none for FRI layer 0 = cp
         assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world
+        halo = 0 if opts.get("exchange_cp") else 2 * (1 << log_b)    # the positions after every block: one small all-gather
+        gathers = st["sent_bytes"] - st["all_to_all_bytes"]
+        assert gathers >= 4.0 * halo * (world - 1)
         if "overlap_min_log" in opts:
             assert st["chunked_layers"] >= 2
         # what ran is what zk_shard_plan announced (the one layout, shared with the mirror)
         import zkstark_amd as zk
-        pl = zk.shard_plan(world, log_n, log_b, **{k: v for k, v in opts.items() if k in ("min_layer_log", "min_chunk_log", "overlap_min_log")})
+        pl = zk.shard_plan(world, log_n, log_b, **{k: v for k, v in opts.items() if k in ("min_layer_log", "min_chunk_log", "overlap_min_log", "exchange_cp")})
+        assert pl["cp_from_f"] == (0 if opts.get("exchange_cp") else 1)
         assert (st["sharded_layers"], st["chunked_layers"], st["all_to_all_bytes"]) == (pl["sharded_layers"], pl["chunked_layers"], pl["all_to_all_bytes"])
 
 
 def test_shard_two_ranks_production_sizes_2e25(orc):
     """Two ranks at the per-rank size of the weak-scaling benchmark (2^24 elements each, domain 2^25) with the
-    production thresholds: f, cp and the next two FRI layers go through the chunked exchange (pieces of 2^23 ... 2^21 words),
-    the 2^21-value layer through a plain one, the rest through the replicated tail.  Every byte of the proof and all 24 roots against the oracle."""
+    production thresholds: f and the two FRI layers after cp go through the chunked exchange (pieces of 2^23 ... 2^21 words; cp
+    itself is recomputed from the received block of f), the 2^21-value layer through a plain one, the rest through the replicated tail.  Every byte of the proof and all 24 roots against the oracle."""
     log_n, world = 22, 2
     want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
     assert want.rc == 0
@@ -281,12 +290,12 @@ def test_shard_two_ranks_production_sizes_2e25(orc):
     for rank, data, state, roots, st in out:
         assert data == want.proof and state == want.state, f"rank {rank}"
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
-        assert st["sharded_layers"] == 5 and st["chunked_layers"] == 4 and st["root_board"] == 1
+        assert st["sharded_layers"] == 5 and st["chunked_layers"] == 3 and st["root_board"] == 1
 
 
 def test_shard_four_ranks_production_sizes_2e26(orc):
     """Four ranks, 2^24 elements each (domain 2^26, the size of BASELINE.json configs[3]), production thresholds:
-    chunked exchange for the pieces of 2^22 and 2^21 words (f, cp, the next FRI layer), single exchanges below, replicated
+    chunked exchange for the pieces of 2^22 and 2^21 words (f and the FRI layer after cp), single exchanges below, replicated
     tail from 2^19 values (layers of >= 2^20 values stay distributed from 4 ranks on)."""
     log_n, world = 23, 4
     want = orc.prove(log_n, 3, want_vectors=False, want_roots=True)
@@ -296,9 +305,9 @@ def test_shard_four_ranks_production_sizes_2e26(orc):
     for rank, data, state, roots, st in out:
         assert data == want.proof and state == want.state, f"rank {rank}"
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
-        assert st["sharded_layers"] == 7 and st["chunked_layers"] == 3 and st["root_board"] == 1
-        words = N + sum(N >> rho for rho in range(7))
-        assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world      # 12 N-ish bytes in total, (G-1)/G of it to peers
+        assert st["sharded_layers"] == 7 and st["chunked_layers"] == 2 and st["root_board"] == 1
+        words = N + sum(N >> rho for rho in range(1, 7))                                # f and FRI layers 1 .. 6; cp comes from the block of f
+        assert st["all_to_all_bytes"] == 4.0 * words / world * (world - 1) / world      # 8 N-ish bytes in total, (G-1)/G of it to peers
 
 
 def test_config4_native_sharded_lde_transpose_commit_2e26(zk, config4_expected):
@@ -381,7 +390,7 @@ def test_shard_ranks_as_threads_with_a_stream_ordered_transport(threads_check, o
 def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
     """The exact configuration `bench.py --gpus 8` proves: domain 2^27, eight ranks of 2^24 elements each, production
     thresholds (0 = defaults) -- here as eight threads on one GPU.  Every rank's bytes equal the single-GPU prover's at
-    2^27 (itself oracle-pinned up to 2^24 and by the strict verifier here); 8 distributed layers (down to 2^20 values: round 5); f and cp (pieces of 2^21 words) in chunks."""
+    2^27 (itself oracle-pinned up to 2^24 and by the strict verifier here); 8 distributed layers (down to 2^20 values: round 5); f (pieces of 2^21 words) in chunks, cp from the received block of f."""
     import subprocess
     import torch
     free, _ = torch.cuda.mem_get_info()
@@ -391,8 +400,9 @@ def test_shard_eight_ranks_at_the_benchmark_size_2e27(threads_check, zk):
     assert out.returncode == 0, out.stdout + out.stderr
     from zkstark_amd import _lib
     plen = _lib.load().zk_proof_data_len(24, 3)
-    assert f"threads ok: world 8, {plen} proof bytes on every rank equal zk_prove; sharded layers 8, chunked 2, board 1" in out.stdout
-    # 12 N-ish bytes in total: f and FRI layers 0..7, 4 bytes per element, (G-1)/G of it to peers
+    assert f"threads ok: world 8, {plen} proof bytes on every rank equal zk_prove; sharded layers 8, chunked 1, board 1" in out.stdout
+    # 8 N-ish bytes in total: f and FRI layers 1..7 (cp = layer 0 comes from the received block of f), 4 bytes per element,
+    # (G-1)/G of it to peers
     N = 1 << 27
-    words = N + sum(N >> rho for rho in range(8))
+    words = N + sum(N >> rho for rho in range(1, 8))
     assert f"all-to-all bytes per rank {4.0 * words / 8 * 7 / 8:.0f}" in out.stdout

@@ -56,7 +56,7 @@ def test_subtree_kernels_register_budget(rows):
     registers, sets their four waves per SIMD); field-hash ones (double precision: the state alone is 32 registers): <= 128,
     i.e. the same four waves per SIMD the LDS allows."""
     sub = [r for r in rows if "merkle_subtree_kernel<" in r["demangled"]]
-    assert len(sub) == 14
+    assert len(sub) == 16                       # leaf sources Plain / Fold / Compose / ComposeBlock / Interleave / the two batch forms + inner, x 2 hashes
     for r in sub:
         assert r["agpr"] == 0
         is_field = r["demangled"].split(">(")[0].rstrip().endswith("1")

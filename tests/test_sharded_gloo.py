@@ -145,7 +145,8 @@ def test_chunked_exchange_multirank(orc, world, log_n, log_b, lists):
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, data, state, n_chunk, n_finish in out:
-        assert n_chunk >= 8 and n_finish >= 2 * 1, "the test must go through the chunked path"
+        # f goes through the chunked exchange (4 chunk builds + 1 finish); cp is recomputed from the received chunks of f
+        assert n_chunk >= 4 and n_finish >= 1, "the test must go through the chunked path"
         assert data == want.proof and state == want.state, f"rank {rank}"
 
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# cp from the received block of f: parity (native tests + mirror), then A/B timing with the ranks-as-threads harness (ZK_HARNESS_EXCHANGE_CP=1: cp exchanged)
+set -o pipefail
+O=gpurun_out/r05cp1; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_shard_native.py tests/test_gpu_sharded.py -x -q > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+tail -3 $O/pytest.log
+gcc -O2 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/shard_threads_check.c -Lzkstark_amd -lzkstark_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/zkstark_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/stc || exit 1
+for cfg in "8 24 3 0 0 0 3" "4 23 3 0 0 0 3" "2 22 3 0 0 0 3" "8 21 3 0 0 0 5" "4 21 3 0 0 0 5" "2 21 3 0 0 0 5"; do
+  for mode in new old new old; do
+    if [ $mode = old ]; then export ZK_HARNESS_EXCHANGE_CP=1; else unset ZK_HARNESS_EXCHANGE_CP; fi
+    echo "== $cfg cp: $mode" >> $O/threads.txt
+    timeout -k 5 90 /tmp/stc $cfg 2>&1 | grep -E "timing|threads ok|rank" >> $O/threads.txt || { echo FAILED >> $O/threads.txt; tail -5 $O/threads.txt; exit 1; }
+  done
+done
+unset ZK_HARNESS_EXCHANGE_CP
+cat $O/threads.txt

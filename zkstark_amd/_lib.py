@@ -43,7 +43,7 @@ class ShardTransport(C.Structure):
 class ShardOptions(C.Structure):
     _fields_ = [("min_layer_log", C.c_uint32), ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32),
                 ("force_collectives", C.c_int), ("no_root_board", C.c_int), ("plain_collectives", C.c_int),
-                ("single_build_stream", C.c_int), ("single_communicator", C.c_int), ("reserved", C.c_int), ("timeout_s", C.c_double)]
+                ("single_build_stream", C.c_int), ("single_communicator", C.c_int), ("exchange_cp", C.c_int), ("timeout_s", C.c_double)]
 
 
 class ShardStats(C.Structure):
@@ -62,7 +62,7 @@ class ShardPlan(C.Structure):
     _fields_ = [("world", C.c_uint32), ("log_world", C.c_uint32), ("sharded_layers", C.c_uint32), ("tail_rounds", C.c_uint32),
                 ("chunked_layers", C.c_uint32), ("chunked_mask", C.c_uint32), ("log_chunks", C.c_uint32), ("min_layer_log", C.c_uint32),
                 ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32), ("piece_log", C.c_uint32 * 32),
-                ("all_to_all_bytes", C.c_double), ("lde_commit_bytes", C.c_double)]
+                ("all_to_all_bytes", C.c_double), ("lde_commit_bytes", C.c_double), ("cp_from_f", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 KERNEL_CLASSES = ("ntt", "merkle_leaf", "merkle_inner", "merkle_top", "compose", "fri_fold", "gather")

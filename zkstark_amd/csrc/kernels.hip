@@ -280,16 +280,16 @@ hipError_t launch_degree_check(const uint32_t* coef, uint32_t log_m, uint32_t nd
 // kInvBatch denominators with one Fermat inversion (Montgomery's trick).
 constexpr int kInvBatch = 8;
 
-__global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, uint32_t logN, PowTable htab, uint32_t w_mont) {
+__global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, size_t count, uint32_t e0, uint32_t order_mask, PowTable htab, uint32_t w_mont) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t N = (size_t)1 << logN, base = gid * kInvBatch;
-    if (base >= N) return;
+    size_t base = gid * kInvBatch;
+    if (base >= count) return;
     uint32_t d[kInvBatch], pre[kInvBatch];
     uint32_t acc = R1;
 #pragma unroll
     for (int e = 0; e < kInvBatch; ++e) {
         size_t i = base + e;
-        uint32_t x = i < N ? mont_mul(pow_lookup(htab, (uint32_t)i), w_mont) : add(R1, R1);
+        uint32_t x = i < count ? mont_mul(pow_lookup(htab, (e0 + (uint32_t)i) & order_mask), w_mont) : add(R1, R1);
         d[e] = sub(x, R1);
         pre[e] = acc;
         acc = mont_mul(acc, d[e]);
@@ -300,15 +300,19 @@ __global__ __launch_bounds__(256) void build_inv_xm1_kernel(uint32_t* out, uint3
         size_t i = base + e;
         uint32_t r = mont_mul(inv, pre[e]);
         inv = mont_mul(inv, d[e]);
-        if (i < N) out[i] = r;
+        if (i < count) out[i] = r;
     }
 }
 
-hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s) {
-    size_t N = (size_t)1 << logN, threads_total = (N + kInvBatch - 1) / kInvBatch;
+hipError_t launch_build_inv_xm1_range(uint32_t* out, size_t count, uint32_t e0, uint32_t log_order, PowTable htab, uint32_t shift_mont, hipStream_t s) {
+    size_t threads_total = (count + kInvBatch - 1) / kInvBatch;
     uint32_t blocks = (uint32_t)((threads_total + 255) / 256);
-    hipLaunchKernelGGL(build_inv_xm1_kernel, dim3(blocks), dim3(256), 0, s, out, logN, htab, shift_mont);
+    if (!blocks) return hipSuccess;
+    hipLaunchKernelGGL(build_inv_xm1_kernel, dim3(blocks), dim3(256), 0, s, out, count, e0, (uint32_t)(((uint64_t)1 << log_order) - 1u), htab, shift_mont);
     return hipGetLastError();
+}
+hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s) {
+    return launch_build_inv_xm1_range(out, (size_t)1 << logN, 0u, logN, htab, shift_mont, s);
 }
 
 // cp(x_i) for x_i = w h^i (prover.rs:101-166 evaluated pointwise; the same formula the
@@ -546,6 +550,31 @@ struct ComposeSrc {    // cp layer 0 from f_eval: prover.rs:101-173 + :176
     __device__ __forceinline__ Raw fetch(size_t pos) const { return pos; }
     __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return load(r); }
     __device__ __forceinline__ uint32_t load(size_t pos) const { uint32_t v = compose_at(a, pos); a.cp[pos] = v; return v; }
+};
+
+struct ComposeBlockSrc {   // cp over this rank's block of a sharded proof, from the block of f it received (ComposeBlockArgs)
+    ComposeBlockArgs b;
+    using Raw = size_t;
+    __device__ __forceinline__ uint32_t f_at(size_t t) const {
+        const uint32_t gmask = (1u << b.lg) - 1u;
+        if (t >> b.log_m) {                                     // the 2B positions after the block
+            const size_t v = t - ((size_t)1 << b.log_m);
+            return b.halo[(v & gmask) * b.halo_stride + (v >> b.lg)];
+        }
+        const uint32_t log_cl = b.lg + b.log_cnt;               // leaves per chunk of the exchange
+        const size_t piece = ((t >> log_cl) << b.lg) | (t & gmask);
+        return b.a.f[(piece << b.log_cnt) | ((t & (((size_t)1 << log_cl) - 1)) >> b.lg)];
+    }
+    __device__ __forceinline__ Raw fetch(size_t pos) const { return pos; }
+    __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return load(r); }
+    __device__ __forceinline__ uint32_t load(size_t pos) const {
+        const ComposeArgs& a = b.a;
+        const size_t B = (size_t)1 << a.log_b;
+        const uint32_t f0 = f_at(pos), f1 = f_at(pos + B), f2 = f_at(pos + 2 * B);
+        const uint32_t x = mont_mul(pow_lookup(a.htab, b.e0 + (uint32_t)pos), a.w_mont);
+        return compose_eval<false>(a, f0, f1, f2, a.inv_xm1[pos], a.inv_xm1[pos + 2 * B], x, a.zz[pos & (B - 1)], a.first, a.last, a.alpha0_mont,
+                                   a.alpha1g2_mont, 0u);
+    }
 };
 
 struct ComposeBatchSrc {   // batch of proofs: leaf b*N + i = cp_b[i], with proof b's own challenges
@@ -1201,6 +1230,12 @@ hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStrea
     return merkle_build_t(ComposeSrc{a}, 8.0 * (double)((size_t)1 << a.logN), a.logN, nodes, s, prof, mail, hash);
 }
 
+// composition over one rank's block of a sharded proof + the subtree over it: reads the block of f (4 bytes per leaf; the
+// taps hit the same lines), the range table (4), writes nothing but the tree
+hipError_t launch_compose_block_merkle(const ComposeBlockArgs& b, uint32_t* nodes, hipStream_t s, Profiler* prof, const MailArgs& mail, int hash) {
+    return merkle_build_t(ComposeBlockSrc{b}, 8.0 * (double)((size_t)1 << b.log_m), b.log_m, nodes, s, prof, mail, hash);
+}
+
 hipError_t launch_compose_merkle_batch(const ComposeBatchArgs& a, uint32_t log_batch, uint32_t* nodes, hipStream_t s, Profiler* prof,
                                        const MailArgs& mail, int hash) {
     uint32_t log_m = a.a.logN + log_batch;
@@ -1388,6 +1423,18 @@ __global__ void interleave_kernel(const uint32_t* in, uint32_t* out, uint32_t lo
     out[o] = in[(q << log_cnt) + u];
 }
 
+__global__ __launch_bounds__(256) void halo_pack_kernel(const uint32_t* loc, uint32_t* out, uint32_t log_per, uint32_t lg, uint32_t h) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (h << lg)) return;
+    const uint32_t q = i / h, u = i - q * h;
+    const size_t mask = ((size_t)1 << (log_per + lg)) - 1;
+    out[i] = loc[((((size_t)q + 1) << log_per) + u) & mask];
+}
+hipError_t launch_halo_pack(const uint32_t* loc, uint32_t* out, uint32_t log_per, uint32_t lg, uint32_t h, hipStream_t s) {
+    const uint32_t total = h << lg;
+    hipLaunchKernelGGL(halo_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, loc, out, log_per, lg, h);
+    return hipGetLastError();
+}
 hipError_t launch_interleave(const uint32_t* in, uint32_t* out, uint32_t log_parts, uint32_t log_cnt, hipStream_t s) {
     size_t total = (size_t)1 << (log_parts + log_cnt);
     uint32_t blocks = (uint32_t)((total + 255) / 256);

@@ -150,6 +150,12 @@ hipError_t launch_degree_check(const uint32_t* coef, uint32_t log_m, uint32_t nd
 
 // inv_xm1[i] = 1 / (shift h^i - 1) in Montgomery form, i < N (domain setup)
 hipError_t launch_build_inv_xm1(uint32_t* out, uint32_t logN, PowTable htab, uint32_t shift_mont, hipStream_t s);
+// the same table over a RANGE of positions: out[t] = 1 / (shift h^((e0 + t) mod 2^log_order) - 1), t < count (the block of a
+// sharded proof: csrc/shard.hip, ComposeBlockArgs)
+hipError_t launch_build_inv_xm1_range(uint32_t* out, size_t count, uint32_t e0, uint32_t log_order, PowTable htab, uint32_t shift_mont, hipStream_t s);
+// Sharded proof, rank r of G = 2^lg: out[q * h + u] = loc[((q + 1) * per + u) mod (G * per)], q < G, u < h -- the values of
+// this rank's cyclic shard that lie in the first G * h positions after the block of rank q (the halo of ComposeBlockArgs)
+hipError_t launch_halo_pack(const uint32_t* loc, uint32_t* out, uint32_t log_per, uint32_t lg, uint32_t h, hipStream_t s);
 hipError_t launch_interleave(const uint32_t* in, uint32_t* out, uint32_t log_parts, uint32_t log_cnt, hipStream_t s);
 
 // Known-pattern exchange of the sharded prover's self-test (shard.hip): word j of the piece rank `from` sends to rank `to`.
@@ -180,6 +186,18 @@ struct ComposeArgs {
     uint32_t zz[32];          // B entries: alpha2 / (x^n - 1) * R^2  (per i mod B)
 };
 hipError_t launch_compose(const ComposeArgs& a, hipStream_t s, Profiler* prof = nullptr);
+
+// cp over ONE RANK'S BLOCK of a sharded proof, computed from the block of f this rank received for the commitment of f
+// (DESIGN.md section 6): position t < 2^log_m of the block is x = w h^(e0 + t); f at t, t + B, t + 2B is read through the
+// all-to-all order of the receive buffer (leaf t of chunk c = t >> (lg + log_cnt): piece (t mod G) of that chunk, word
+// (t mod 2^(lg + log_cnt)) >> lg), the 2B positions after the block from `halo` (an all-gather of what launch_halo_pack
+// wrote: value v at halo[(v mod G) * halo_stride + (v >> lg)]).  a.f = the receive buffer, a.inv_xm1 = the range table
+// (2^log_m + 2B entries from e0), a.htab / a.w_mont / a.log_b / a.zz = the GLOBAL domain's; a.cp is not written.
+struct ComposeBlockArgs {
+    ComposeArgs a;
+    const uint32_t* halo;
+    uint32_t lg, log_cnt, log_m, halo_stride, e0;
+};
 
 struct FoldArgs {
     const uint32_t* in;   // m values
@@ -232,6 +250,9 @@ hipError_t launch_fold_merkle(const FoldArgs& a, uint32_t* nodes, hipStream_t s,
                               const MailArgs& mail = MailArgs{}, int hash = 0);
 hipError_t launch_compose_merkle(const ComposeArgs& a, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
                                  const MailArgs& mail = MailArgs{}, int hash = 0);
+// the same for a block of a sharded proof (ComposeBlockArgs): the subtree over this rank's 2^log_m leaves of cp
+hipError_t launch_compose_block_merkle(const ComposeBlockArgs& b, uint32_t* nodes, hipStream_t s, Profiler* prof = nullptr,
+                                       const MailArgs& mail = MailArgs{}, int hash = 0);
 
 // ---- batched proving: 2^log_batch proofs of one size in lockstep ------------------
 // Layer l of the batch is stored proof-major, [batch][m_l]; the 2^log_batch trees over it are the bottom of

@@ -130,6 +130,13 @@ struct zk_shard {
     static constexpr uint32_t kLogChunks = 2;          // chunked layers: 4 chunks
     uint32_t n_sharded = 1, tail_rounds = 0, chunked_mask = 0;   // zk_shard_plan
     zk_dom* dom_loc = nullptr;
+    // cp is committed WITHOUT an exchange (zk_shard_plan_info.cp_from_f): the block of f this rank received for the commitment
+    // of f is still in the receive buffer, so cp over the block is recomputed from it inside the leaf hashing; the 2B positions
+    // after the block come from a 2B-word all-gather (the halo), 1/(x - 1) over the block from a table built at creation
+    bool cp_from_f = false;
+    zk_dom* dom_glob = nullptr;                        // fold-only: the global domain's power table and constants
+    uint32_t *d_inv_blk = nullptr, *d_halo_send = nullptr, *d_halo = nullptr;
+    hipEvent_t ev_halo = nullptr;
     zk_ctx* tail = nullptr;
     zk_committer* committer = nullptr;
     uint32_t *d_trace = nullptr, *d_coef = nullptr, *d_layers = nullptr, *d_trees = nullptr;
@@ -389,7 +396,42 @@ int commit_wait_failed(zk_shard* s, uint32_t lid, int rc) {
 
 // Cyclic layer `lid` (2^m_log values in total, 2^m_log / G here) -> subtree over this rank's block of leaves;
 // root_out: the root of the whole tree (prover.rs:81, :176, :214 + what :85 / :180 / :224 feed the channel).
-int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[32]) {
+// the G subtree roots, on the host of every rank: through the shared page, else by all-gather; the top log2 G levels are
+// hashed by every rank (merkle.rs:14-51 on G leaves that are digests)
+int join_subtrees(zk_shard* s, uint32_t lid, uint32_t* nodes, const uint8_t mine_bytes[32], uint8_t root_out[32]) {
+    const int G = s->G;
+    int rc;
+    uint32_t mine[8];
+    Digest dm;
+    bytes_to_digest(mine_bytes, dm);
+    memcpy(mine, dm.w, 32);
+    std::vector<uint32_t> sub((size_t)G * 8);
+    if (!collectives(s)) {
+        memcpy(sub.data(), mine, 32);
+    } else if (s->use_board) {
+        const RootBoard::Status bs = s->board.exchange(++s->board_seq, mine, sub.data(), s->timeout_s);
+        if (bs == RootBoard::kPeerAborted)
+            return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d (seen in root exchange #%llu, layer %u)", s->rank, G,
+                        s->board.bad_peer, -(int)s->board.bad_code, (unsigned long long)s->board_seq, lid);
+        if (bs != RootBoard::kOk)
+            return fail(ZK_ERR_HIP, "rank %d of %d: rank %d did not post its subtree root of layer %u (root exchange #%llu timed out after %.0f s)", s->rank, G,
+                        s->board.bad_peer, lid, (unsigned long long)s->board_seq, s->timeout_s);
+    } else {
+        if ((rc = all_gather(s, nodes, s->d_small, 8, s->stream))) return rc;   // node 0 of every rank's subtree
+        HIPCHK(hipMemcpyAsync(s->h_small, s->d_small, 32 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
+        if ((rc = sync_peers(s, s->stream, "the all-gather of the subtree roots"))) return rc;
+        memcpy(sub.data(), s->h_small, 32 * (size_t)G);
+    }
+    host_merkle_top(sub.data(), G, s->tops[lid], s->hash);
+    digest_words_to_bytes(s->tops[lid].data(), root_out);
+    return ZK_OK;
+}
+
+// halo: this is the commitment of f inside a proof whose cp is computed from the received block (cp_from_f): behind the
+// exchange(s) of the layer, in the same program order on every rank, goes the 2B-word all-gather of the positions after
+// every block (packed from the cyclic shard by the caller).  It runs on the stream the LAST exchange ran on, so beside the
+// hashing when the layer is exchanged in chunks; the main stream picks it up at ev_halo.
+int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[32], bool halo = false) {
     const int G = s->G;
     const uint32_t lg = s->lg;
     uint32_t* loc = layer_ptr(s, lid);
@@ -436,6 +478,10 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
                 }
                 if ((rc = zk_dev_merkle_build_chunk(s->d_recv + (size_t)c * G * cc, lg, log_cnt - lk, nodes, m_log - lg, c, bs, s->hash))) return rc;
                 if (bs != s->stream) HIPCHK(hipEventRecord(s->ev_built[c], bs));
+                if (halo && c + 1 == K) {
+                    if ((rc = all_gather(s, s->d_halo_send, s->d_halo, 2 * s->B, xs))) return rc;
+                    HIPCHK(hipEventRecord(s->ev_halo, xs));
+                }
             }
             if (two)
                 for (uint32_t c = 1; c < K; c += 2) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_built[c], 0));
@@ -444,36 +490,47 @@ int commit_sharded(zk_shard* s, uint32_t lid, uint32_t m_log, uint8_t root_out[3
         } else {
             for (int g = 0; g < G; ++g) { send[g] = loc + (size_t)g * per; recv[g] = s->d_recv + (size_t)g * per; }
             if ((rc = all_to_all(s, send, recv, per, s->stream))) return rc;   // piece q: rank q's share of my block
+            if (halo) {
+                if ((rc = all_gather(s, s->d_halo_send, s->d_halo, 2 * s->B, s->stream))) return rc;
+                HIPCHK(hipEventRecord(s->ev_halo, s->stream));
+            }
             if ((rc = zk_dev_merkle_commit(s->committer, s->d_recv, lg, log_cnt, nodes, s->stream, s->hash, mine_bytes))) return commit_wait_failed(s, lid, rc);
         }
     } else {
         if ((rc = zk_dev_merkle_commit(s->committer, loc, 0, m_log, nodes, s->stream, s->hash, mine_bytes))) return rc;
     }
-    // the G subtree roots, on the host of every rank
-    uint32_t mine[8];
-    Digest dm;
-    bytes_to_digest(mine_bytes, dm);
-    memcpy(mine, dm.w, 32);
-    std::vector<uint32_t> sub((size_t)G * 8);
-    if (!collectives(s)) {
-        memcpy(sub.data(), mine, 32);
-    } else if (s->use_board) {
-        const RootBoard::Status bs = s->board.exchange(++s->board_seq, mine, sub.data(), s->timeout_s);
-        if (bs == RootBoard::kPeerAborted)
-            return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d (seen in root exchange #%llu, layer %u)", s->rank, G,
-                        s->board.bad_peer, -(int)s->board.bad_code, (unsigned long long)s->board_seq, lid);
-        if (bs != RootBoard::kOk)
-            return fail(ZK_ERR_HIP, "rank %d of %d: rank %d did not post its subtree root of layer %u (root exchange #%llu timed out after %.0f s)", s->rank, G,
-                        s->board.bad_peer, lid, (unsigned long long)s->board_seq, s->timeout_s);
-    } else {
-        if ((rc = all_gather(s, nodes, s->d_small, 8, s->stream))) return rc;   // node 0 of every rank's subtree
-        HIPCHK(hipMemcpyAsync(s->h_small, s->d_small, 32 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
-        if ((rc = sync_peers(s, s->stream, "the all-gather of the subtree roots"))) return rc;
-        memcpy(sub.data(), s->h_small, 32 * (size_t)G);
-    }
-    host_merkle_top(sub.data(), G, s->tops[lid], s->hash);
-    digest_words_to_bytes(s->tops[lid].data(), root_out);
-    return ZK_OK;
+    return join_subtrees(s, lid, nodes, mine_bytes, root_out);
+}
+
+// cp_from_f: the subtree over this rank's block of cp, computed from the block of f in the receive buffer (which the
+// commitment of f left in all-to-all order, in chunks if that layer was exchanged in chunks) and the gathered halo
+int commit_cp_from_f(zk_shard* s, const uint32_t alpha[3], uint8_t root_out[32]) {
+    const uint32_t lg = s->lg, L = s->L;
+    const bool chunked = (s->chunked_mask & 1u) != 0;
+    ComposeBlockArgs g{};
+    g.a.f = s->d_recv;
+    g.a.inv_xm1 = s->d_inv_blk;
+    g.halo = s->d_halo + (size_t)s->rank * ((2 * s->B) >> lg);
+    g.lg = lg;
+    g.log_cnt = L - 2 * lg - (chunked ? zk_shard::kLogChunks : 0u);
+    g.log_m = L - lg;
+    g.halo_stride = (uint32_t)(2 * s->B);
+    g.e0 = (uint32_t)((size_t)s->rank << (L - lg));
+    HIPCHK(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+    uint8_t mine_bytes[32];
+    uint32_t* nodes = tree_ptr(s, 1);
+    // The folds need cp over this rank's CYCLIC shard (prover.rs:166-173 on the local coset): that sweep goes behind the hashing
+    // on the same stream, before this thread waits for the digests, so it runs while the roots are exchanged.  (On the second
+    // build stream, beside the hashing, it cost 0.1 ms per proof more: measured, tools/ab_cp_from_f.py.)
+    struct Ctx { zk_shard* s; const uint32_t* alpha; } cx{s, alpha};
+    const int rc = dev_compose_block_commit(s->committer, s->dom_glob, g, s->first, s->last, alpha, nodes, s->stream, s->hash, mine_bytes,
+                                            [](void* u) -> int {
+                                                Ctx* c = static_cast<Ctx*>(u);
+                                                return zk_dev_compose(c->s->dom_loc, layer_ptr(c->s, 0), layer_ptr(c->s, 1), c->s->first, c->s->last, c->alpha,
+                                                                      c->s->stream);
+                                            }, &cx);
+    if (rc) return commit_wait_failed(s, 1, rc);
+    return join_subtrees(s, 1, nodes, mine_bytes, root_out);
 }
 
 int do_lde(zk_shard* s) { return zk_dev_lde(s->dom_loc, s->d_trace, s->d_coef, layer_ptr(s, 0), s->stream); }
@@ -637,13 +694,22 @@ int prove(zk_shard* s, Channel& ch) {
     reset_timing(s);
     ch.data.reserve(ch.data.size() + proof_data_len(s->log_n, s->log_b, s->queries));
     if ((rc = do_lde(s))) return rc;                                              // prover.rs:60-70
-    if ((rc = commit_sharded(s, 0, L, root))) return rc;                           // prover.rs:81
+    if (s->cp_from_f)                                                              // what every block's neighbour needs of my shard
+        HIPCHK(launch_halo_pack(layer_ptr(s, 0), s->d_halo_send, L - 2 * lg, lg, (uint32_t)((2 * s->B) >> lg), s->stream));
+    if ((rc = commit_sharded(s, 0, L, root, s->cp_from_f))) return rc;             // prover.rs:81
     ch.commit_hash(root);                                                          // prover.rs:85
     memcpy(s->info.roots[0], root, 32);
     uint32_t alpha[3];
     for (int i = 0; i < 3; ++i) alpha[i] = s->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
-    if ((rc = zk_dev_compose(s->dom_loc, layer_ptr(s, 0), layer_ptr(s, 1), s->first, s->last, alpha, s->stream))) return rc;   // :166-173
-    if ((rc = commit_sharded(s, 1, L, root))) return rc;                           // prover.rs:176
+    if (s->cp_from_f) {
+        // prover.rs:166-176 twice over: the commitment needs cp over this rank's BLOCK, the folds need it over its cyclic
+        // shard.  The block of f is still in the receive buffer (nothing has been exchanged since), so the block form is
+        // computed inside the leaf hashing; the cyclic form follows on the stream while the host waits for the root.
+        if ((rc = commit_cp_from_f(s, alpha, root))) return rc;
+    } else {
+        if ((rc = zk_dev_compose(s->dom_loc, layer_ptr(s, 0), layer_ptr(s, 1), s->first, s->last, alpha, s->stream))) return rc;   // :166-173
+        if ((rc = commit_sharded(s, 1, L, root))) return rc;                       // prover.rs:176
+    }
     ch.commit_hash(root);                                                          // prover.rs:180
     memcpy(s->info.roots[1], root, 32);
     uint32_t free_term = 0;
@@ -825,12 +891,17 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
     out->min_layer_log = min_layer_log; out->min_chunk_log = min_chunk_log; out->overlap_min_log = overlap_min_log;
     out->log_chunks = zk_shard::kLogChunks;
     const bool coll = world > 1 || force;
+    // cp over a rank's block is a function of f over the block and the 2B positions after it: with the block of f already
+    // there (the commitment of f), cp is committed without an exchange.  Needs blocks of >= 2B leaves made of pieces of
+    // >= 2B / G words (n >= 2 G); `exchange_cp` keeps the exchange (rounds 1-4; A/B).
+    out->cp_from_f = (coll && !(opt && opt->exchange_cp) && ((size_t)1 << log_n) >= 2 * (size_t)world) ? 1u : 0u;
     // committed distributed layers: id 0 = f, id 1 + rho = FRI layer rho < ns; layer id has 2^m_log values in total
     for (uint32_t lid = 0; lid <= ns && lid < 32; ++lid) {
         const uint32_t m_log = lid == 0 ? L : L - (lid - 1);
         const uint32_t log_cnt = m_log - 2 * lg;                     // words per (rank, peer) piece
         const bool chunked = coll && log_cnt >= overlap_min_log && log_cnt >= zk_shard::kLogChunks + 8;
         out->piece_log[lid] = log_cnt;
+        if (lid == 1 && out->cp_from_f) continue;                    // cp is recomputed from the received block of f: no exchange
         if (chunked) { out->chunked_mask |= 1u << lid; out->chunked_layers += 1; }
         const double sent = coll ? 4.0 * (double)((size_t)1 << log_cnt) * (world - 1) : 0.0;   // to the world - 1 peers
         out->all_to_all_bytes += sent;
@@ -870,6 +941,10 @@ int zk_shard_destroy(zk_shard* s) {
     if (s->tail) zk_ctx_destroy(s->tail);
     if (s->committer) zk_committer_destroy(s->committer);
     if (s->dom_loc) zk_dom_destroy(s->dom_loc);
+    if (s->dom_glob) zk_dom_destroy(s->dom_glob);
+    for (void* p : {(void*)s->d_inv_blk, (void*)s->d_halo_send, (void*)s->d_halo})
+        if (p) (void)hipFree(p);
+    if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);
     for (void* p : {(void*)s->d_trace, (void*)s->d_coef, (void*)s->d_layers, (void*)s->d_trees, (void*)s->d_recv, (void*)s->d_gbuf,
                     (void*)s->d_repl, (void*)s->d_small, (void*)s->d_goff, (void*)s->d_gout, (void*)s->d_gall})
         if (p) (void)hipFree(p);
@@ -938,6 +1013,7 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     s->n_sharded = ns;
     s->tail_rounds = plan.tail_rounds;
     s->chunked_mask = plan.chunked_mask;
+    s->cp_from_f = plan.cp_from_f != 0;
     (void)R;
     HIPCHK_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     {   // the exchanges run beside the hashing: their workgroups should win the CU slots the hashing frees
@@ -1009,6 +1085,17 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     if ((rc = zk_dom_create(device, log_n, log_b - lg, shift, 0, &s->dom_loc))) return bail(rc);
     if ((rc = zk_tail_create(device, s->tail_rounds, log_b, powmod(GEN_W, (uint64_t)1 << ns), &s->tail))) return bail(rc);
     if ((rc = zk_committer_create(device, &s->committer))) return bail(rc);
+    if (s->cp_from_f) {
+        // cp over this rank's block from the block of f it receives: the global domain's constants, 1/(x - 1) at the positions
+        // of the block and of the 2B after it (x = w h^(rank N/G + t)), and the buffers of the halo all-gather
+        const size_t M = s->N >> lg, blk = M + 2 * s->B;
+        if ((rc = zk_dom_create(device, log_n, log_b, GEN_W, 1, &s->dom_glob))) return bail(rc);
+        if ((rc = dalloc(s, &s->d_inv_blk, blk * 4)) || (rc = dalloc(s, &s->d_halo_send, 2 * s->B * 4)) ||
+            (rc = dalloc(s, &s->d_halo, 2 * s->B * 4 * (size_t)world)))
+            return bail(rc);
+        HIPCHK_S(launch_build_inv_xm1_range(s->d_inv_blk, blk, (uint32_t)((size_t)rank * M), L, s->dom_glob->H.view(), s->dom_glob->shift_mont, s->stream));
+        HIPCHK_S(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
+    }
     // layers: 0 = f, 1 + rho = FRI layer rho < ns (distributed); one allocation for layers, one for trees
     const size_t NL = s->N >> lg;
     size_t off = 0;

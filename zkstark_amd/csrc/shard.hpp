@@ -17,5 +17,9 @@ const RcclApi* rccl_api();                 // nullptr + fail() recorded when the
 // timeout_s > 0: also the bound of that wait
 void committer_set_poll(zk_committer* k, int (*poll)(void*), void* user, double timeout_s = 0.0);
 
+// zkstark.hip: cp over one rank's block from the block of f it received, and the subtree over it (ComposeBlockArgs)
+int dev_compose_block_commit(zk_committer* k, const zk_dom* glob, ComposeBlockArgs geom, uint32_t first, uint32_t last, const uint32_t alpha_raw[3],
+                             uint32_t* d_nodes, hipStream_t s, int hash_kind, uint8_t root_out[32], int (*enqueued)(void*) = nullptr, void* user = nullptr);
+
 }  // namespace impl
 }  // namespace zk

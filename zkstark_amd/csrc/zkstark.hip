@@ -1366,6 +1366,41 @@ int zk_dev_merkle_commit(zk_committer* k, const uint32_t* d_src, uint32_t log_pa
     return committer_collect(k, m, d_nodes, s, root_out);
 }
 
+// cp over this rank's block of a sharded proof, computed from the block of f it holds in all-to-all order, and the
+// subtree over it (kernels.hpp: ComposeBlockArgs; prover.rs:101-176 on the positions of the block).  glob: the GLOBAL
+// domain (fold-only is enough: power table, x^n - 1 values, g^-k); geom: halo, lg, log_cnt, log_m, halo_stride, e0 and
+// geom.a.f / geom.a.inv_xm1 (receive buffer, range table) filled in by the caller; everything else of geom.a is set here.
+// enqueued (optional) is called between the launches and the wait for the posted digests.
+extern "C++" {
+namespace zk {
+namespace impl {
+int dev_compose_block_commit(zk_committer* k, const zk_dom* glob, ComposeBlockArgs geom, uint32_t first, uint32_t last, const uint32_t alpha_raw[3],
+                             uint32_t* d_nodes, hipStream_t s, int hash_kind, uint8_t root_out[32], int (*enqueued)(void*), void* user) {
+    if (!k || !glob || !geom.a.f || !geom.a.inv_xm1 || !geom.halo || !d_nodes || !root_out || (hash_kind != 0 && hash_kind != 1) ||
+        geom.log_m > 30 || geom.lg + geom.log_cnt > geom.log_m)
+        return fail(ZK_ERR_INVALID, "dev_compose_block_commit: bad argument");
+    if (((size_t)1 << geom.log_m) < 2 * glob->B || geom.halo_stride < (2 * glob->B) >> geom.lg)
+        return fail(ZK_ERR_INVALID, "dev_compose_block_commit: a block of 2^%u leaves is shorter than the 2B = %zu taps", geom.log_m, 2 * glob->B);
+    HIPCHK(hipSetDevice(k->device));
+    const uint32_t* f = geom.a.f;
+    const uint32_t* inv = geom.a.inv_xm1;
+    int rc = compose_args(glob, f, nullptr, first, last, alpha_raw, geom.a);
+    if (rc) return rc;
+    geom.a.inv_xm1 = inv;
+    MailArgs m;
+    m.mailbox = k->d_mail;
+    m.seq = ++k->seq;
+    m.counter = k->d_counter;
+    m.top = (hash_kind == 0 && k->top && geom.log_m > k->top) ? k->top : 0;
+    HIPCHK(launch_compose_block_merkle(geom, d_nodes, s, dev_prof(), m, hash_kind));
+    if (enqueued)                                   // the caller's next launches go behind the hashing before this thread waits for the digests
+        if ((rc = enqueued(user))) return rc;
+    return committer_collect(k, m, d_nodes, s, root_out);
+}
+}  // namespace impl
+}  // namespace zk
+}  // extern "C++"
+
 // The same hand-over for a tree built in chunks (zk_dev_merkle_build_chunk): the latency-bound top of the
 // whole tree down to depth `top` on the device, the rest on the calling thread, root returned.
 int zk_dev_merkle_commit_finish(zk_committer* k, uint32_t* d_nodes, uint32_t log_m, uint32_t log_chunks, void* stream, int hash_kind,
