@@ -21,6 +21,12 @@ if [ -f $O/bench_sharded_1rank.json ]; then
     { echo "# the STRONG shape on the same harness: one 2^24 proof over 8 / 4 / 2 ranks (threads of one process sharing one GPU), min_layer_log swept."
       echo "# 'per rank' = total / G is a LOWER bound of a rank's time on its own GPU: the replicated parts (the tail below min_layer_log, the size-n iNTT, the decommitment) are in it G times and do not shrink with G."
       cat $O/shard_threads_strong.txt; } > $P/r05_shard_threads_strong.txt
+    { echo "# tools/ab_cp_from_f.py 21 (one MI355X; one rank, collectives forced through RCCL; 2^24-point proof; two repetitions, alternating)."
+      echo "# cp 'from f': recomputed over the rank's block from the received block of f (default, round 5); 'exchanged': zk_shard_options.exchange_cp (rounds 1-4)."
+      echo "# At ONE rank the exchange of a rank with itself is RCCL's transport kernel at ~0.14 TB/s: exchange_ms is what drops.  Kernel timeline: r05_cp_from_f_timeline.txt."
+      grep "^cp" $O/ab_cp_from_f.txt
+      echo "# ranks as threads of one process sharing the GPU (tests/shard_threads_check.c <world> <log_n> 3 0 0 0 3; 'old' = ZK_HARNESS_EXCHANGE_CP=1):"
+      cat $O/ab_cp_threads.txt; } > $P/r05_ab_cp_from_f.txt
     grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" $O/soak.txt > $P/r05_soak.txt
 fi
 biggest() { python3 - "$1" "$2" <<'PY'

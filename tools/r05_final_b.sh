@@ -12,6 +12,8 @@ ZK_BENCH_STAGED=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 -
 gcc -O2 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/shard_threads_check.c -Lzkstark_amd -lzkstark_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/zkstark_amd -Wl,-rpath,/opt/rocm/lib -o tools/shard_threads_check
 for rep in 1 2 3; do for w in "8 24" "4 23" "2 22"; do timeout -k 10 300 ./tools/shard_threads_check $w 3 0 0 0 3 2>&1 | grep -E "timing|threads ok" >> $O/shard_threads_timing.txt; done; done
 for w in 8 4 2; do for ml in 0 20 23; do echo "# strong shape: a 2^24 proof over $w ranks (threads of one process, one GPU), min_layer_log=$ml (0 = the default: 20 from 4 ranks on, else 21)" >> $O/shard_threads_strong.txt; timeout -k 10 120 ./tools/shard_threads_check $w 21 3 $ml 0 0 5 2>&1 | grep -E "timing|threads ok|rank" >> $O/shard_threads_strong.txt; done; done
+timeout -k 10 200 python tools/ab_cp_from_f.py 21 > $O/ab_cp_from_f.txt 2>&1; echo "ab cp_from_f rc=$?"
+for rep in 1 2; do for m in new old; do if [ $m = old ]; then export ZK_HARNESS_EXCHANGE_CP=1; else unset ZK_HARNESS_EXCHANGE_CP; fi; for w in "8 24" "4 23" "2 22"; do echo "== world/log_n $w, cp: $m" >> $O/ab_cp_threads.txt; timeout -k 10 300 ./tools/shard_threads_check $w 3 0 0 0 3 2>&1 | grep -E "timing" >> $O/ab_cp_threads.txt; done; done; done; unset ZK_HARNESS_EXCHANGE_CP
 timeout -k 10 200 python tools/soak.py 40 > $O/soak.txt 2>&1; echo "soak rc=$?" | tee -a $O/soak.txt
 timeout -k 10 300 python tools/shard_soak.py 2 14 200 >> $O/soak.txt 2>&1; echo "shard soak rc=$?" | tee -a $O/soak.txt
 timeout -k 10 300 python tools/shard_rccl_soak.py 16 300 >> $O/soak.txt 2>&1; echo "rccl soak rc=$?" | tee -a $O/soak.txt

@@ -7,6 +7,9 @@
 // all-to-all turns the cyclic layout into contiguous blocks of m/G leaves (chunk q of the receive buffer comes
 // from rank q; leaf u*G + q of the block = recv[q][u], hashed straight from the receive buffer), each rank builds
 // its subtree, the G subtree roots are exchanged and the top log2(G) levels are hashed on the host by every rank.
+// cp is the exception (round 5): over a rank's block it is a function of f over that block and the 2B positions after it,
+// and the block of f is still in the receive buffer when cp is due, so it is recomputed there inside the leaf hashing
+// (commit_cp_from_f) and only a 2B-word all-gather travels: 8N instead of 12N bytes per proof on the links.
 // Small layers are replicated and finished in one call (zk_tail_*).  The transcript runs identically on every rank.
 //
 // The collectives go through a two-function transport: RCCL (grouped ncclSend/ncclRecv over xGMI, loaded at run
