@@ -19,7 +19,7 @@
 
 #include "zkstark_amd.h"
 
-#define MAXW 16
+#define MAXW 32
 static int g_world;
 /* A barrier the ranks can be released from: a rank that fails sets g_abort and never arrives, the others leave the
  * barrier with an error instead of waiting for it for ever (the transport then reports the failure to the library). */

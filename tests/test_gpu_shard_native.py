@@ -355,6 +355,10 @@ def threads_check(tmp_path_factory):
     (16, 14, 4, (1, 4, 9)),       # lg = 4
     (2, 13, 3, (1, 5, 9)),
     (4, 15, 2, (1, 5, 9)),
+    (32, 12, 5, (1, 2, 99)),      # lg = 5 = log2 of the blow-up: 32 ranks, the halo of cp is 2 words per (rank, block)
+    (8, 4, 3, (1, 1, 99)),        # n = 2 G: a block is exactly the 2B taps long, pieces of two words
+    (4, 4, 2, (1, 1, 99)),
+    (2, 2, 3, (1, 1, 99)),
 ])
 def test_shard_ranks_as_threads_of_one_process(threads_check, orc, world, log_n, log_b, thresholds):
     """world = 8 and 16 natively on one GPU: the ranks are threads of one C process (the model of

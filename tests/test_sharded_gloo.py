@@ -77,8 +77,21 @@ def test_sharded_prover_matches_oracle(orc, world, log_n, log_b, min_chunk_log):
         assert roots == [bytes(r).hex() for r in want.roots], f"rank {rank}: roots differ"
         assert data == want.proof and state == want.state, f"rank {rank}: proof differs from the oracle"
         assert calls["lde"] == 2 and calls["compose"] == 2 and calls["fold"] == 2 * log_n          # two proofs
+        assert calls["compose_block"] == 2, "cp must be committed from the received block of f, not exchanged"
         assert calls["board_exchanges"] == 2 * (n_sharded + 1), "subtree roots must travel through the shared-memory board"
     assert orc.verify(res[0][1], log_n, log_b, want.public_last) == 0
+
+
+@pytest.mark.parametrize("world,log_n,log_b", [(8, 4, 3), (4, 4, 2), (2, 2, 3)])
+def test_sharded_cp_from_f_at_the_smallest_blocks(orc, world, log_n, log_b):
+    """cp over a rank's block from the received block of f, at the edge of what the layout allows: n = 2 G (a block is
+    exactly the 2B taps long: every f(g x), f(g^2 x) of its last B positions comes from the gathered halo), pieces of two words."""
+    want = orc.prove(log_n, log_b)
+    assert want.rc == 0
+    for rank, data, state, n_sharded, calls, roots in _run(world, log_n, log_b, 1, 1):
+        assert calls["compose_block"] == 2
+        assert roots == [bytes(r).hex() for r in want.roots], f"rank {rank}: roots differ"
+        assert data == want.proof and state == want.state, f"rank {rank}"
 
 
 def test_sharded_without_root_board(orc):
