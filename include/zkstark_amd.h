@@ -386,7 +386,8 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_blowup, const zk_shard
  * collective of the other stream, so no ordering rests on RCCL's internal serialisation.  A caller transport is called
  * with either stream and must tolerate that.
  * zk_shard_create ends with a self-test when collectives are in use: an all-to-all (on each stream in use) and an
- * all-gather of a known pattern at the size of the largest piece; every word must arrive at its place, else the call
+ * all-gather (on the main stream, and on the exchange stream when the halo of cp travels there) of a known pattern, the
+ * all-to-all at the size of the largest piece; every word must arrive at its place, else the call
  * fails with ZK_ERR_HIP naming the first wrong (peer, word).  It also brings RCCL's lazy connections up before the
  * first proof.  zk_shard_self_test repeats it on request.
  * ncclCommInitRank itself is not bounded by this library (it cannot be cancelled): a caller that must not hang runs

@@ -812,16 +812,33 @@ int self_test(zk_shard* s) {
         HIPCHK(hipStreamWaitEvent(s->stream, s->ev_chunk[0], 0));
         if ((rc = verdict("the chunked all-to-all on the exchange stream", lk))) return rc;
     }
-    // all-gather: 16 words per rank
-    for (uint32_t j = 0; j < 16; ++j) s->h_small[j] = shard_pattern((uint32_t)s->rank, 0xA6u, j);
-    HIPCHK(hipMemcpyAsync(s->d_small, s->h_small, 64, hipMemcpyHostToDevice, s->stream));
-    if ((rc = all_gather(s, s->d_small, s->d_small + 64, 16, s->stream))) return rc;
-    HIPCHK(hipMemcpyAsync(s->h_small + 64, s->d_small + 64, 64 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
-    if ((rc = sync_peers(s, s->stream, "the self-test all-gather"))) return rc;
-    for (int q = 0; q < G; ++q)
-        for (uint32_t j = 0; j < 16; ++j)
-            if (s->h_small[64 + 16 * q + j] != shard_pattern((uint32_t)q, 0xA6u, j))
-                return fail(ZK_ERR_HIP, "rank %d of %d: self-test of the all-gather failed: word %u of rank %d's part is wrong", s->rank, G, j, q);
+    // all-gather: 16 words per rank, on the main stream and -- if the halo of cp will travel there (cp_from_f with f exchanged
+    // in chunks) -- on the exchange stream with its communicator
+    auto gather_check = [&](hipStream_t st, uint32_t tag, const char* what) -> int {
+        for (uint32_t j = 0; j < 16; ++j) s->h_small[j] = shard_pattern((uint32_t)s->rank, tag, j);
+        HIPCHK(hipMemcpyAsync(s->d_small, s->h_small, 64, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->d_small + 64, 0, 64 * (size_t)G, s->stream));
+        if (st != s->stream) {
+            HIPCHK(hipEventRecord(s->ev_layer, s->stream));
+            HIPCHK(hipStreamWaitEvent(st, s->ev_layer, 0));
+        }
+        int r2 = all_gather(s, s->d_small, s->d_small + 64, 16, st);
+        if (r2) return r2;
+        if (st != s->stream) {
+            HIPCHK(hipEventRecord(s->ev_chunk[0], st));
+            HIPCHK(hipStreamWaitEvent(s->stream, s->ev_chunk[0], 0));
+        }
+        HIPCHK(hipMemcpyAsync(s->h_small + 64, s->d_small + 64, 64 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
+        if ((r2 = sync_peers(s, s->stream, what))) return r2;
+        for (int q = 0; q < G; ++q)
+            for (uint32_t j = 0; j < 16; ++j)
+                if (s->h_small[64 + 16 * q + j] != shard_pattern((uint32_t)q, tag, j))
+                    return fail(ZK_ERR_HIP, "rank %d of %d: self-test of %s failed: word %u of rank %d's part is wrong", s->rank, G, what, j, q);
+        return ZK_OK;
+    };
+    if ((rc = gather_check(s->stream, 0xA6u, "the all-gather on the main stream"))) return rc;
+    if (s->cp_from_f && (s->chunked_mask & 1u))
+        if ((rc = gather_check(s->xstream, 0x6Au, "the all-gather on the exchange stream"))) return rc;
     s->stats.selftest_ok = 1;
     s->stats.selftest_ms = (now_us() - t0) * 1e-3;
     return ZK_OK;
