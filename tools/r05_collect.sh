@@ -50,5 +50,7 @@ python3 -c "
 import json
 d = json.load(open('$P/traffic.json')); print('traffic.json:', d['commit'], d['build_hash'], round(d['merkle_leaf_bytes_per_launch'] / 1e6, 1), 'MB per leaf launch')
 b = json.load(open('$P/r05_bench_2e24.json')); print('bench:', round(b['ms_per_step'], 3), 'ms per proof, device-only', round(b['ms_per_step_device_only'], 3), 'parity_checked', b['parity_checked'], 'build', b['build_hash'], 'traffic from this build', b['roofline']['traffic_from_this_build'])
+lb = b['batched_2e24'].get('larger_batches', {})
+print('  larger batches:', lb.get('proofs'), round(lb.get('ms_per_proof', 0), 3), round(lb.get('two_batches_in_flight', {}).get('ms_per_proof', 0), 3), lb.get('two_batches_in_flight', {}).get('frac_of_hashing_floor'))
 print('  batched_2e24', round(b['batched_2e24']['ms_per_proof'], 3), round(b['batched_2e24']['two_batches_in_flight']['ms_per_proof'], 3), 'cfg2', round(b['lde_commit_2e20']['us'], 1), round(b['lde_commit_2e20']['us_sustained'], 1), 'frac', round(b['roofline']['frac'], 3))
 f = json.load(open('$P/r05_bench_2e24_fieldhash.json')); print('field:', round(f['ms_per_step'], 2), 'ms per proof, parity_checked', f['parity_checked'], 'build', f['build_hash'])"
