@@ -420,6 +420,7 @@ int join_subtrees(zk_shard* s, uint32_t lid, uint32_t* nodes, const uint8_t mine
             return fail(ZK_ERR_HIP, "rank %d of %d: rank %d did not post its subtree root of layer %u (root exchange #%llu timed out after %.0f s)", s->rank, G,
                         s->board.bad_peer, lid, (unsigned long long)s->board_seq, s->timeout_s);
     } else {
+        if ((rc = committer_flush(s->committer, s->stream))) return rc;         // node 0 is host-built: on the device before it is gathered
         if ((rc = all_gather(s, nodes, s->d_small, 8, s->stream))) return rc;   // node 0 of every rank's subtree
         HIPCHK(hipMemcpyAsync(s->h_small, s->d_small, 32 * (size_t)G, hipMemcpyDeviceToHost, s->stream));
         if ((rc = sync_peers(s, s->stream, "the all-gather of the subtree roots"))) return rc;
@@ -524,7 +525,8 @@ int commit_cp_from_f(zk_shard* s, const uint32_t alpha[3], uint8_t root_out[32])
     uint32_t* nodes = tree_ptr(s, 1);
     // The folds need cp over this rank's CYCLIC shard (prover.rs:166-173 on the local coset): that sweep goes behind the hashing
     // on the same stream, before this thread waits for the digests, so it runs while the roots are exchanged.  (On the second
-    // build stream, beside the hashing, it cost 0.1 ms per proof more: measured, tools/ab_cp_from_f.py.)
+    // build stream, beside the hashing, it cost 0.1 ms per proof more; on a LOW-priority stream of its own 0.15-0.6 ms more:
+    // measured, tools/ab_cp_from_f.py.)
     struct Ctx { zk_shard* s; const uint32_t* alpha; } cx{s, alpha};
     const int rc = dev_compose_block_commit(s->committer, s->dom_glob, g, s->first, s->last, alpha, nodes, s->stream, s->hash, mine_bytes,
                                             [](void* u) -> int {
@@ -695,6 +697,7 @@ int prove(zk_shard* s, Channel& ch) {
     s->stats.sent_bytes = s->stats.all_to_all_bytes = 0;
     s->stats.chunked_layers = 0;
     reset_timing(s);
+    committer_drop_pending(s->committer);
     ch.data.reserve(ch.data.size() + proof_data_len(s->log_n, s->log_b, s->queries));
     if ((rc = do_lde(s))) return rc;                                              // prover.rs:60-70
     if (s->cp_from_f)                                                              // what every block's neighbour needs of my shard
@@ -754,6 +757,7 @@ int prove(zk_shard* s, Channel& ch) {
     uint32_t qraws[kMaxQueries];
     for (uint32_t k = 0; k < s->queries; ++k) qraws[k] = ch.get_u32();            // prover.rs:263 (x queries)
     s->info.query_raw = qraws[0];
+    if ((rc = committer_flush(s->committer, s->stream))) return rc;               // the host-built tree tops: one launch, now that whole trees are read
     for (uint32_t k = 0; k < s->queries; ++k)                                      // prover.rs:266-289 per query
         if ((rc = decommit(s, ch, (size_t)qraws[k] % (s->N - 2 * s->B)))) return rc;
     collect_timing(s);
@@ -1146,6 +1150,10 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     HIPCHK_S(hipHostGetDevicePointer((void**)&s->dm_fmail, s->h_fmail, 0));
     if ((rc = dalloc(s, &s->d_fcounter, 64))) return bail(rc);
     HIPCHK_S(hipMemsetAsync(s->d_fcounter, 0, 64, s->stream));
+    // Tree tops built on the host reach the device with ONE launch per proof, before the decommitment, instead of one launch per
+    // commitment in front of the next layer's kernels (4.7 us + a launch gap on the path of every commitment: one rank through RCCL
+    // 6.02 -> 5.93 ms per 2^24 proof)
+    committer_set_lazy(s->committer, s->d_trees);
     s->tops.resize(ns + 1);
     s->device_bytes += (double)zk_ctx_device_bytes(s->tail);
     // A shared-memory page when every rank can map the object (one node): the abort words always, and the subtree roots
@@ -1224,8 +1232,10 @@ int zk_shard_lde_commit(zk_shard* s, uint8_t root_out[32]) {
     s->stats.chunked_layers = 0;
     if (s->failed) return fail(ZK_ERR_STATE, "zk_shard_lde_commit: this rank left an earlier call with an error; destroy the prover");
     reset_timing(s);
+    committer_drop_pending(s->committer);
     int rc = do_lde(s);                                         // prover.rs:60-70, each rank its cosets
     if (!rc) rc = commit_sharded(s, 0, s->L, root_out);         // the all-to-all transpose + prover.rs:81
+    if (!rc) rc = committer_flush(s->committer, s->stream);     // the tree of f complete on the device
     if (!rc) collect_timing(s);
     return rank_failed(s, rc);
 }

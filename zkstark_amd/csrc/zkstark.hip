@@ -1267,9 +1267,19 @@ struct zk_committer {
     uint32_t* h_mail = nullptr;     // pinned, mapped: MailArgs layout
     uint32_t* d_mail = nullptr;
     uint32_t* d_counter = nullptr;
-    uint32_t* h_stage = nullptr;    // pinned, mapped: host-built top nodes, then one ScatterSeg
+    uint32_t* h_stage = nullptr;    // pinned, mapped: host-built top nodes of up to kSlots commits, then kSlots ScatterSegs
     uint32_t* d_stage = nullptr;
     uint32_t seq = 0, top = 0;
+    // lazy mode (committer_set_lazy; the sharded prover): the host-built tops of successive commits collect in the staging
+    // buffer and ONE scatter launch copies them into the tree array when somebody needs whole trees on the device
+    // (committer_flush) -- not one launch per commit in front of the caller's next kernel.  base: the array every d_nodes of
+    // a lazy commit points into.
+    static constexpr uint32_t kSlots = 40;
+    static constexpr size_t kSlotWords = (size_t)8 << kHostTopSingle;
+    bool lazy = false;
+    uint32_t* base = nullptr;
+    uint32_t n_pending = 0;
+    double pending_words = 0;
     // h_stage is read by the scatter launch of the previous commit, which may sit on ANY stream the caller passed:
     // its completion is awaited (an event, normally long signalled) before the next commit overwrites the buffer
     hipEvent_t stage_free = nullptr;
@@ -1304,7 +1314,8 @@ int zk_committer_create(int device, zk_committer** out) {
     zk_committer* k = new (std::nothrow) zk_committer();
     if (!k) return fail(ZK_ERR_NOMEM, "out of host memory");
     k->device = device;
-    const size_t stage_bytes = ((size_t)16 << kMaxHostLog) * 4 + sizeof(ScatterSeg);
+    static_assert(zk_committer::kSlots * zk_committer::kSlotWords >= ((size_t)16 << kMaxHostLog), "staging: one eager commit fits");
+    const size_t stage_bytes = zk_committer::kSlots * zk_committer::kSlotWords * 4 + zk_committer::kSlots * sizeof(ScatterSeg);
     hipError_t e = hipHostMalloc((void**)&k->h_mail, kMailValsOff * 4, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&k->d_mail, k->h_mail, 0);
     if (e == hipSuccess) e = hipHostMalloc((void**)&k->h_stage, stage_bytes, hipHostMallocMapped | hipHostMallocCoherent);
@@ -1327,23 +1338,62 @@ int zk_committer_set_top(zk_committer* k, uint32_t top_log) {
 }
 // Waits for the digests a commit launch posted; with a hand-over depth, hashes the levels above on this thread
 // and queues the copy of those nodes into d_nodes.
+static ScatterSeg* committer_segs(zk_committer* k, bool device) {
+    return reinterpret_cast<ScatterSeg*>((device ? k->d_stage : k->h_stage) + zk_committer::kSlots * zk_committer::kSlotWords);
+}
+// lazy mode: ONE scatter launch for the host-built tops collected since the last flush
+static int committer_flush_impl(zk_committer* k, hipStream_t s) {
+    if (!k->n_pending) return ZK_OK;
+    HIPCHK(launch_scatter(k->d_stage, committer_segs(k, true), k->n_pending, k->pending_words, k->base, nullptr, s, dev_prof()));
+    HIPCHK(hipEventRecord(k->stage_free, s));
+    k->stage_busy = true;
+    k->n_pending = 0;
+    k->pending_words = 0;
+    return ZK_OK;
+}
 static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nodes, hipStream_t s, uint8_t root_out[32]) {
     int rc = wait_flag(k->h_mail, m.seq, s, k->poll, k->poll_user, k->timeout_s);
     if (rc) return rc;
     if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
     const size_t cnt = (size_t)1 << m.top;
-    uint32_t* nodes = k->h_stage;
-    if (k->stage_busy) { HIPCHK(hipEventSynchronize(k->stage_free)); k->stage_busy = false; }   // previous scatter done with h_stage
+    const bool lazy = k->lazy && k->base && d_nodes >= k->base;
+    if (lazy && k->n_pending == zk_committer::kSlots)
+        if ((rc = committer_flush_impl(k, s))) return rc;
+    if (k->stage_busy && (!lazy || k->n_pending == 0)) {      // the previous scatter launch is done with the staging buffer
+        HIPCHK(hipEventSynchronize(k->stage_free));
+        k->stage_busy = false;
+    }
+    const uint32_t slot = lazy ? k->n_pending : 0u;
+    uint32_t* nodes = k->h_stage + (size_t)slot * zk_committer::kSlotWords;
     memcpy(nodes + 8 * (cnt - 1), k->h_mail + kMailDigests, cnt * 32);
     host_sha_reduce(nodes, m.top);
     digest_words_to_bytes(nodes, root_out);
-    ScatterSeg* seg = reinterpret_cast<ScatterSeg*>(k->h_stage + ((size_t)16 << kMaxHostLog));
-    *seg = ScatterSeg{0, 0, (uint32_t)((cnt - 1) * 8), 0};
-    HIPCHK(launch_scatter(k->d_stage, reinterpret_cast<ScatterSeg*>(k->d_stage + ((size_t)16 << kMaxHostLog)), 1, (double)seg->words,
-                          d_nodes, nullptr, s, dev_prof()));
+    ScatterSeg* seg = committer_segs(k, false) + slot;
+    *seg = ScatterSeg{(uint64_t)slot * zk_committer::kSlotWords, lazy ? (uint64_t)(d_nodes - k->base) : 0u, (uint32_t)((cnt - 1) * 8), 0};
+    if (lazy) {
+        k->n_pending += 1;
+        k->pending_words += (double)seg->words;
+        return ZK_OK;
+    }
+    HIPCHK(launch_scatter(k->d_stage, committer_segs(k, true), 1, (double)seg->words, d_nodes, nullptr, s, dev_prof()));
     HIPCHK(hipEventRecord(k->stage_free, s));
     k->stage_busy = true;
     return ZK_OK;
+}
+extern "C++" {
+namespace zk { namespace impl {
+void committer_set_lazy(zk_committer* k, uint32_t* trees_base) {
+    if (k) { k->lazy = trees_base != nullptr; k->base = trees_base; }
+}
+int committer_flush(zk_committer* k, hipStream_t s) {
+    if (!k) return ZK_OK;
+    HIPCHK(hipSetDevice(k->device));
+    return committer_flush_impl(k, s);
+}
+void committer_drop_pending(zk_committer* k) {
+    if (k) { k->n_pending = 0; k->pending_words = 0; }
+}
+} }
 }
 
 // Tree over 2^(log_parts + log_cnt) leaves (log_parts = 0: d_src in natural order; else in all-to-all order as
