@@ -531,7 +531,7 @@ def main():
     lib = _lib.load()
 
     def dev_stats():
-        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
+        arr = _lib.kernel_stat_array()
         _lib.check(lib.zk_dev_kernel_stats(arr, len(arr), 1))
         return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes, "ops": a.ops} for name, a in zip(_lib.KERNEL_CLASSES, arr)}
 

@@ -30,6 +30,8 @@ pub fn generate_proof(channel: Channel) -> Proof {
 
     let (state, data) = channel.into_parts(); // pub(crate) accessor added to channel.rs
     unsafe {
+        // the library on the path must speak the ABI these declarations were generated from (include/zkstark_amd.h)
+        assert_eq!(zk_abi_version(), ZK_ABI_VERSION, "libzkstark_amd.so was built from another zkstark_amd.h");
         let mut ctx = std::ptr::null_mut();
         check(zk_ctx_create(0, 10, 3, &mut ctx)); // n = 1024, blow-up 8 (prover.rs:48-57)
         let mut ch = std::ptr::null_mut();

@@ -31,6 +31,10 @@ static double now_ms(void) {
 int main(int argc, char **argv) {
     const uint32_t log_n = 10, log_b = 3;                              /* prover.rs:48-57 */
     uint32_t log_batch = argc > 1 ? (uint32_t)atoi(argv[1]) : 6;
+    if (zk_abi_version() != ZK_ABI_VERSION) {                           /* the library on the path was built from another zkstark_amd.h */
+        fprintf(stderr, "libzkstark_amd speaks ABI version %u, this program was compiled against %u\n", zk_abi_version(), ZK_ABI_VERSION);
+        return 2;
+    }
     zk_batch *b = NULL;
     CHECK(zk_batch_create(0, log_n, log_b, log_batch, &b));
     size_t batch = zk_batch_size(b), plen = zk_proof_data_len(log_n, log_b);

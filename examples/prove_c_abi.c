@@ -29,6 +29,10 @@ static double now_ms(void) {
 int main(int argc, char **argv) {
     uint32_t log_n = argc > 1 ? (uint32_t)atoi(argv[1]) : 10;      /* prover.rs:32, :48: trace 1023, group 1024 */
     uint32_t log_b = argc > 2 ? (uint32_t)atoi(argv[2]) : 3;       /* prover.rs:49: domain 8192 */
+    if (zk_abi_version() != ZK_ABI_VERSION) {                           /* the library on the path was built from another zkstark_amd.h */
+        fprintf(stderr, "libzkstark_amd speaks ABI version %u, this program was compiled against %u\n", zk_abi_version(), ZK_ABI_VERSION);
+        return 2;
+    }
     size_t n = (size_t)1 << log_n;
     uint32_t *trace = malloc((n - 1) * sizeof *trace);
     CHECK(zk_trace_fibsq(1, 3141592, n - 1, trace));               /* prover.rs:32-39 */

@@ -29,7 +29,8 @@ static void *run_rank(void *p) {
     rank_args *a = p;
     zk_shard *sp = NULL;
     zk_shard_options opt;
-    memset(&opt, 0, sizeof opt);
+    ZK_STRUCT_INIT(&opt);                               /* zeroes it and sets opt.struct_size = sizeof opt (checked by the library) */
+    ZK_STRUCT_INIT(&a->stats);
     opt.force_collectives = 1;                          /* with world = 1: still go through RCCL */
     if (a->log_n + a->log_b < 22) { opt.min_layer_log = 1; opt.min_chunk_log = 6; }   /* small demo sizes: shard anyway */
     a->rc = zk_shard_create(a->rank /* GPU */, a->rank, a->world, a->id, NULL /* RCCL */, &opt, a->log_n, a->log_b, &sp);
@@ -45,6 +46,10 @@ int main(int argc, char **argv) {
     int world = argc > 1 ? atoi(argv[1]) : 1;
     uint32_t log_n = argc > 2 ? (uint32_t)atoi(argv[2]) : 12, log_b = argc > 3 ? (uint32_t)atoi(argv[3]) : 3;
     if (world < 1 || world > 8) { fprintf(stderr, "world must be 1..8\n"); return 2; }
+    if (zk_abi_version() != ZK_ABI_VERSION) {           /* the library on the path was built from another zkstark_amd.h */
+        fprintf(stderr, "libzkstark_amd speaks ABI version %u, this program was compiled against %u\n", zk_abi_version(), ZK_ABI_VERSION);
+        return 2;
+    }
     size_t n = (size_t)1 << log_n, cap = zk_proof_data_len(log_n, log_b);
     uint32_t *trace = malloc((n - 1) * sizeof *trace);
     if (zk_trace_fibsq(1, 3141592, n - 1, trace)) return 1;          /* prover.rs:32-39 */

@@ -28,6 +28,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>   /* ZK_STRUCT_INIT */
 
 #ifdef __cplusplus
 extern "C" {
@@ -57,6 +58,22 @@ enum zk_hash_kind { ZK_HASH_SHA256 = 0, ZK_HASH_FIELD = 1 };
 
 const char *zk_last_error(void);
 const char *zk_version(void);
+
+/* ---- ABI version and caller-allocated structs -------------------------------------------------------------------
+ * The reference has no FFI, so the rules of this seam are the build's own:
+ *   - ZK_ABI_VERSION changes whenever an exported signature or the layout of a struct below changes incompatibly; a caller
+ *     compiled against this header checks zk_abi_version() == ZK_ABI_VERSION once at start-up (the C programs under examples/ and tests/ do);
+ *   - every struct the CALLER allocates (zk_transcript_info, zk_kernel_stat, zk_shard_options, zk_shard_stats,
+ *     zk_shard_plan_info, zk_chain_probe) starts with `uint32_t struct_size`, which the caller sets to sizeof(the struct) as
+ *     its own compiler sees it (ZK_STRUCT_INIT zeroes the struct and sets it) BEFORE every call, for outputs as well as for
+ *     inputs.  The library reads / writes at most struct_size bytes and refuses (ZK_ERR_INVALID, zk_last_error names the
+ *     struct and both sizes) a size of 0 or one below the struct's size in ABI version 6 (the first with this rule): a
+ *     caller compiled against an older, smaller layout gets an error instead of shifted fields or a stack overwrite;
+ *   - new fields are appended at the END only, so a caller compiled against a smaller (>= version 6) layout keeps working:
+ *     input fields it does not know are taken as 0 (= default), output fields it does not know are not written. */
+#define ZK_ABI_VERSION 6u
+uint32_t zk_abi_version(void);
+#define ZK_STRUCT_INIT(ptr) (memset((ptr), 0, sizeof *(ptr)), (ptr)->struct_size = (uint32_t)sizeof *(ptr))
 /* Hash of the sources and headers the library was built from (zkstark_amd/build.py: source_hash()); loaders
  * compare it with the tree to refuse a stale binary. */
 const char *zk_build_hash(void);
@@ -178,6 +195,7 @@ int zk_prove(zk_ctx *ctx, const uint32_t *trace, size_t count, uint8_t *proof_ou
              size_t *proof_len, uint8_t state_out[32]);
 /* Challenges and checkpoints of the last zk_prove* on this context (tests/diagnostics). */
 typedef struct zk_transcript_info {
+    uint32_t struct_size;   /* sizeof(zk_transcript_info), set by the caller (see "ABI version" above) */
     uint32_t alpha_raw[3];
     uint32_t beta_raw[32];
     uint32_t free_term;
@@ -200,6 +218,8 @@ enum zk_kernel_class {
     ZK_K_COUNT = 7
 };
 typedef struct zk_kernel_stat {
+    uint32_t struct_size;   /* sizeof(zk_kernel_stat), set by the caller in out[0]: the stride of the array */
+    uint32_t reserved;
     uint64_t launches;
     double ms;     /* summed launch durations */
     double bytes;  /* summed ALGORITHMIC bytes of those launches */
@@ -315,7 +335,8 @@ typedef struct zk_shard_transport {
     /* recv[q * words ..] = rank q's send */
     int (*all_gather)(void *user, const uint32_t *send, uint32_t *recv, size_t words, void *stream);
 } zk_shard_transport;
-typedef struct zk_shard_options {   /* zero = default */
+typedef struct zk_shard_options {   /* zero = default (struct_size excepted) */
+    uint32_t struct_size;       /* sizeof(zk_shard_options), set by the caller (see "ABI version" above) */
     uint32_t min_layer_log;     /* a FRI layer stays sharded while it has >= 2^this values in total (21; 20 from 4 ranks on) */
     uint32_t min_chunk_log;     /* ... and >= 2^this leaves per (rank, peer) piece (14) */
     uint32_t overlap_min_log;   /* pieces of >= 2^this words are exchanged in 4 chunks overlapped with the hashing (21) */
@@ -332,6 +353,7 @@ typedef struct zk_shard_options {   /* zero = default */
     double timeout_s;           /* bound of every host-side wait on a peer; 0 = environment ZK_SHARD_TIMEOUT_S, else 120 s */
 } zk_shard_options;
 typedef struct zk_shard_stats {
+    uint32_t struct_size;       /* sizeof(zk_shard_stats), set by the caller (see "ABI version" above) */
     uint32_t sharded_layers;    /* FRI layers 0 .. sharded_layers-1 (and f) are distributed; the rest is the replicated tail */
     uint32_t root_board;        /* 1: subtree roots travel through shared memory (all ranks on one node) */
     uint32_t chunked_layers;    /* layers of the last proof exchanged in chunks overlapped with the hashing */
@@ -360,6 +382,7 @@ typedef struct zk_shard_stats {
 /* The layout of a sharded proof, as a pure function of its arguments (no GPU, no communication): what
  * zk_shard_create will do.  Layer ids: 0 = f_eval, 1 + r = FRI layer r. */
 typedef struct zk_shard_plan_info {
+    uint32_t struct_size;        /* sizeof(zk_shard_plan_info), set by the caller (see "ABI version" above) */
     uint32_t world;
     uint32_t log_world;
     uint32_t sharded_layers;     /* FRI layers 0 .. sharded_layers-1 (and f) are distributed */
@@ -442,6 +465,8 @@ int zk_dev_kernel_stats(zk_kernel_stat *out, size_t count, int reset);
  * launches back to back.  ns_per_hash_per_simd is the steady-state time one SIMD needs per hash of one wave; divided
  * by the hash's VALU instruction count it is the issue rate the Merkle kernels can reach at best at that residency. */
 typedef struct zk_chain_probe {
+    uint32_t struct_size;          /* sizeof(zk_chain_probe), set by the caller (see "ABI version" above) */
+    uint32_t reserved;
     double ns_per_hash_per_simd;
     double clock_ghz;              /* median over the waves: shader clocks per 100 MHz reference tick */
     double ms;                     /* wall time of the timed launches (HIP events) */

@@ -6,6 +6,12 @@
  *   gcc -O2 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/shard_threads_check.c \
  *       -Lzkstark_amd -lzkstark_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/zkstark_amd -Wl,-rpath,/opt/rocm/lib -o shard_threads_check
  *   ./shard_threads_check world log_n log_blowup min_layer_log min_chunk_log overlap_min_log [timed_reps [fail_rank]]
+ * A harness binary does not outlive the library it was compiled against: it refuses to run when the library's ABI version
+ * differs from its header's, and -- when compiled with -DZK_EXPECT_BUILD_HASH=\"<zk_build_hash of the library>\" (the
+ * tests and tools/run_shard_threads.sh do) -- when the library was built from other sources.  Every caller-allocated
+ * struct carries its size (ZK_STRUCT_INIT), so a stale binary gets ZK_ERR_INVALID instead of shifted fields.  Every
+ * host-side wait of the library is bounded by opt.timeout_s = 20 s (environment ZK_HARNESS_TIMEOUT_S), so that a stuck
+ * exchange names rank, peer and layer on stderr well before an outer `timeout` would kill the process silently.
  */
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
@@ -25,11 +31,20 @@ static int g_world;
  * barrier with an error instead of waiting for it for ever (the transport then reports the failure to the library). */
 static atomic_int g_abort, g_count, g_gen;
 static int g_fail_rank = -1;                  /* argv[8]: this rank injects a failure instead of proving */
+static double g_timeout_s = 20.0;             /* also zk_shard_options.timeout_s of every rank */
+static double mono_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 static int bar_wait(void) {
     const int gen = atomic_load(&g_gen);
     if (atomic_fetch_add(&g_count, 1) + 1 == g_world) { atomic_store(&g_count, 0); atomic_fetch_add(&g_gen, 1); return 0; }
+    const double t0 = mono_s();
+    unsigned spins = 0;
     while (atomic_load(&g_gen) == gen) {
         if (atomic_load(&g_abort)) return 1;
+        if ((++spins & 1023) == 0 && mono_s() - t0 > g_timeout_s) {   /* the harness's own waits are bounded like the library's */
+            fprintf(stderr, "harness barrier #%d: %d of %d ranks arrived within %.0f s; giving up\n", gen, atomic_load(&g_count), g_world, g_timeout_s);
+            atomic_store(&g_abort, 1);
+            return 1;
+        }
         sched_yield();
     }
     return 0;
@@ -129,6 +144,7 @@ static void *run_rank(void *p) {
     if (g_async && (hipSetDevice(0) != hipSuccess || async_events(a->rank))) { a->rc = ZK_ERR_HIP; snprintf(a->err, sizeof a->err, "event creation failed"); atomic_store(&g_abort, 1); return NULL; }
     zk_shard_transport tp = {&u, tp_all_to_all, tp_all_gather};
     zk_shard *sp = NULL;
+    a->stats.struct_size = (uint32_t)sizeof a->stats;
     a->rc = zk_shard_create(0, a->rank, g_world, a->id, &tp, &a->opt, a->log_n, a->log_b, &sp);
     if (!a->rc) a->rc = zk_shard_trace_upload(sp, a->trace, ((size_t)1 << a->log_n) - 1);
     if (!a->rc && a->rank == g_fail_rank) a->rc = zk_shard_inject_failure(sp, ZK_ERR_STATE);   /* leaves the proof; peers must not hang */
@@ -149,6 +165,18 @@ static void *run_rank(void *p) {
 
 int main(int argc, char **argv) {
     if (argc < 7) { fprintf(stderr, "usage: world log_n log_blowup min_layer_log min_chunk_log overlap_min_log\n"); return 2; }
+    if (zk_abi_version() != ZK_ABI_VERSION) {
+        fprintf(stderr, "stale harness: libzkstark_amd speaks ABI version %u, this binary was compiled against %u -- recompile it\n", zk_abi_version(), ZK_ABI_VERSION);
+        return 2;
+    }
+#ifdef ZK_EXPECT_BUILD_HASH
+    if (strcmp(zk_build_hash(), ZK_EXPECT_BUILD_HASH)) {
+        fprintf(stderr, "stale harness: compiled for library build %s, the library on the path is %s -- recompile it\n", ZK_EXPECT_BUILD_HASH, zk_build_hash());
+        return 2;
+    }
+#endif
+    if (getenv("ZK_HARNESS_TIMEOUT_S") && atof(getenv("ZK_HARNESS_TIMEOUT_S")) > 0) g_timeout_s = atof(getenv("ZK_HARNESS_TIMEOUT_S"));
+    const double timeout_s = g_timeout_s;
     g_world = atoi(argv[1]);
     const uint32_t log_n = (uint32_t)atoi(argv[2]), log_b = (uint32_t)atoi(argv[3]);
     if (g_world < 1 || g_world > MAXW) return 2;
@@ -164,6 +192,8 @@ int main(int argc, char **argv) {
     for (int r = 0; r < g_world; ++r) {
         memset(&args[r], 0, sizeof args[r]);
         args[r].rank = r; args[r].log_n = log_n; args[r].log_b = log_b; args[r].id = id; args[r].trace = trace;
+        ZK_STRUCT_INIT(&args[r].opt);
+        args[r].opt.timeout_s = timeout_s;
         args[r].opt.min_layer_log = (uint32_t)atoi(argv[4]); args[r].opt.min_chunk_log = (uint32_t)atoi(argv[5]);
         args[r].opt.overlap_min_log = (uint32_t)atoi(argv[6]);
         args[r].opt.exchange_cp = getenv("ZK_HARNESS_EXCHANGE_CP") ? 1 : 0;   /* A/B: cp exchanged like every other layer (rounds 1-4) */

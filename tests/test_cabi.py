@@ -329,3 +329,111 @@ def test_tuning_surface_is_calls_not_environment(zk):
     assert names == {"ZK_HOST_TIMING", "ZK_SHARD_TIMEOUT_S"}, names
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert all(n in doc for n in names)
+
+
+# ---- ABI version and caller-allocated structs (include/zkstark_amd.h) ------------------------------------------------------
+ABI_STRUCTS = {"zk_transcript_info": "TranscriptInfo", "zk_kernel_stat": "KernelStat", "zk_shard_options": "ShardOptions",
+               "zk_shard_stats": "ShardStats", "zk_shard_plan_info": "ShardPlan", "zk_chain_probe": "ChainProbe"}
+
+
+def test_abi_version_and_struct_sizes_agree_everywhere(zk, tmp_path):
+    """One ABI version in the header, the library and the ctypes mirror; every caller-allocated struct starts with struct_size,
+    and its size as gcc lays it out equals the ctypes mirror's and the library's version-6 minimum (csrc/internal.hpp: AbiMin)."""
+    import subprocess
+    from zkstark_amd import _lib
+    header = open(os.path.join(ROOT, "include", "zkstark_amd.h")).read()
+    ver = int(re.search(r"#define\s+ZK_ABI_VERSION\s+(\d+)u", header).group(1))
+    assert _lib.load().zk_abi_version() == ver == _lib.ABI_VERSION
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "zkstark_amd.h"\nint main(void) {\n' +
+                   "".join(f'    printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, struct_size));\n' for n in ABI_STRUCTS) +
+                   "    zk_shard_options o; ZK_STRUCT_INIT(&o); return o.struct_size == sizeof o && o.timeout_s == 0 ? 0 : 1;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    internal = open(os.path.join(ROOT, "zkstark_amd", "csrc", "internal.hpp")).read()
+    for line in out.splitlines():
+        name, size, off = line.split()
+        mirror = getattr(_lib, ABI_STRUCTS[name])
+        assert int(off) == 0 and mirror._fields_[0][0] == "struct_size"
+        assert int(size) == C.sizeof(mirror), (name, size, C.sizeof(mirror))
+        amin = int(re.search(r"AbiMin<%s>\s*\{ static constexpr uint32_t v = (\d+);" % name, internal).group(1))
+        assert amin <= int(size), name              # == today; a struct may only grow at its end
+        assert mirror().struct_size == int(size)
+
+
+def test_stale_or_unsized_structs_are_refused(zk):
+    """A caller compiled against an older header passes a smaller struct (or one that never set struct_size): the library answers
+    ZK_ERR_INVALID naming the struct and both sizes instead of reading / writing past it (round 5's zk_shard_stats grew in the
+    middle).  A LARGER struct (a newer caller) is accepted and the bytes the library does not know stay untouched."""
+    from zkstark_amd import _lib
+    lib = _lib.load()
+    plan_fn = lib.zk_shard_plan
+    saved = plan_fn.argtypes
+    plan_fn.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    try:
+        good_opt, good_plan = _lib.ShardOptions(), _lib.ShardPlan()
+        assert plan_fn(2, 22, 3, C.byref(good_opt), C.byref(good_plan)) == 0 and good_plan.sharded_layers == 5
+        # output struct: size 0 (never set: the round-5 layout began with `world`), the round-5 size, an absurd size
+        for bad in (0, C.sizeof(_lib.ShardPlan) - 8, 1 << 20):
+            pl = _lib.ShardPlan()
+            pl.struct_size = bad
+            pl.world = 777
+            assert plan_fn(2, 22, 3, None, C.byref(pl)) == -1
+            msg = lib.zk_last_error().decode()
+            assert "zk_shard_plan_info.struct_size" in msg and str(bad) in msg and str(C.sizeof(_lib.ShardPlan)) in msg, msg
+            assert pl.world == 777                                     # nothing was written
+        # input struct: the same rule
+        for bad in (0, C.sizeof(_lib.ShardOptions) - 8):
+            opt = _lib.ShardOptions()
+            opt.struct_size = bad
+            assert plan_fn(2, 22, 3, C.byref(opt), C.byref(_lib.ShardPlan())) == -1
+            assert "zk_shard_options.struct_size" in lib.zk_last_error().decode()
+        # a larger struct from a newer caller: fields the library knows are filled, the tail is left alone
+
+        class BiggerPlan(C.Structure):
+            _fields_ = [("base", _lib.ShardPlan), ("future", C.c_uint8 * 24)]
+        big = BiggerPlan()
+        C.memset(C.byref(big), 0xAB, C.sizeof(big))
+        big.base.struct_size = C.sizeof(big)
+        assert plan_fn(2, 22, 3, None, C.byref(big)) == 0
+        assert big.base.sharded_layers == 5 and big.base.struct_size == C.sizeof(big) and bytes(big.future) == b"\xab" * 24
+        assert bytes(big.base)[4:] == bytes(good_plan)[4:]
+
+        class BiggerOpt(C.Structure):
+            _fields_ = [("base", _lib.ShardOptions), ("future", C.c_uint32 * 4)]
+        bo = BiggerOpt()
+        bo.base.struct_size = C.sizeof(bo)
+        bo.base.plain_collectives = 1
+        bo.future[0] = 12345                                           # an option this library does not know: ignored
+        pl = _lib.ShardPlan()
+        assert plan_fn(8, 24, 3, C.byref(bo), C.byref(pl)) == 0 and pl.overlap_min_log == 99
+    finally:
+        plan_fn.argtypes = saved
+    # the harness and the examples check the version and size their structs (what the r05i session lacked)
+    for rel in ("tests/shard_threads_check.c", "examples/shard_c_abi.c", "examples/prove_c_abi.c", "examples/batch_c_abi.c"):
+        text = open(os.path.join(ROOT, rel)).read()
+        assert "zk_abi_version() != ZK_ABI_VERSION" in text, rel
+    harness = open(os.path.join(ROOT, "tests", "shard_threads_check.c")).read()
+    assert "ZK_STRUCT_INIT(&args[r].opt)" in harness and "opt.timeout_s = timeout_s" in harness and "ZK_EXPECT_BUILD_HASH" in harness
+
+
+def test_a_stale_harness_binary_refuses_to_run(zk, tmp_path):
+    """tests/shard_threads_check.c compiled for another build of the library (what shipped to the GPU box in round 5's killed
+    session: a git-ignored binary under tools/ that a script did not recompile) names the mismatch and exits before it touches
+    the GPU; compiled by the one recipe (tools/build_shard_threads_check.sh) it gets as far as the missing GPU."""
+    import subprocess
+    inc = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include")]
+    link = ["-L" + os.path.join(ROOT, "zkstark_amd"), "-lzkstark_amd", "-L/opt/rocm/lib", "-lamdhip64",
+            "-Wl,-rpath," + os.path.join(ROOT, "zkstark_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    stale = str(tmp_path / "stale")
+    subprocess.check_call(["gcc", "-O1", "-pthread", '-DZK_EXPECT_BUILD_HASH="0123456789abcdef01234567"'] + inc +
+                          [os.path.join(ROOT, "tests", "shard_threads_check.c")] + link + ["-o", stale])
+    out = subprocess.run([stale, "2", "10", "3", "1", "1", "99"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "stale harness: compiled for library build 0123456789abcdef01234567" in out.stderr, out.stderr
+    fresh = str(tmp_path / "fresh")
+    subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_shard_threads_check.sh"), fresh], stdout=subprocess.DEVNULL)
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([fresh, "2", "10", "3", "1", "1", "99"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 1 and "stale harness" not in out.stderr and "rank 0: -2" in out.stderr, out.stderr

@@ -343,9 +343,8 @@ def test_shard_from_plain_c(tmp_path, orc):
 def threads_check(tmp_path_factory):
     import subprocess
     exe = str(tmp_path_factory.mktemp("shard") / "shard_threads_check")
-    subprocess.check_call(["gcc", "-O2", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "shard_threads_check.c"), "-L" + os.path.join(ROOT, "zkstark_amd"), "-lzkstark_amd",
-                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "zkstark_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    # one recipe for tests and session scripts: stamped with the library's build hash, so a stale binary refuses to run
+    subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_shard_threads_check.sh"), exe], stdout=subprocess.DEVNULL)
     return exe
 
 

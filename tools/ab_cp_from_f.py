@@ -16,7 +16,7 @@ with zk.Context(log_n, 3) as c:
 
 
 def dev_stats():
-    arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
+    arr = _lib.kernel_stat_array()
     _lib.check(lib.zk_dev_kernel_stats(arr, len(arr), 1))
     return {name: (int(a.launches), a.ms) for name, a in zip(_lib.KERNEL_CLASSES, arr)}
 

@@ -126,6 +126,15 @@ def render(consts, opaque, structs, fns):
         L += ["#[repr(C)]", "#[derive(Clone, Copy)]", f"pub struct {name} {{"]
         L += [f"    pub {f}: {t}," for f, t in fields]
         L += ["}", ""]
+        if fields and fields[0][0] == "struct_size":      # caller-allocated struct of the ABI: ZK_STRUCT_INIT
+            L += [f"impl {name} {{",
+                  "    /// ZK_STRUCT_INIT: all fields zero, struct_size = size_of::<Self>() (the library checks it before every read or write).",
+                  "    pub fn new() -> Self {",
+                  "        let mut s: Self = unsafe { std::mem::zeroed() };",
+                  "        s.struct_size = std::mem::size_of::<Self>() as u32;",
+                  "        s",
+                  "    }",
+                  "}", ""]
     L += ['#[link(name = "zkstark_amd")]', 'extern "C" {']
     for name, params, ret in fns:
         sig = ", ".join(f"{p}: {t}" for p, t in params)

@@ -22,13 +22,27 @@ class ZkError(RuntimeError):
         self.code = code
 
 
-class TranscriptInfo(C.Structure):
-    _fields_ = [("alpha_raw", C.c_uint32 * 3), ("beta_raw", C.c_uint32 * 32), ("free_term", C.c_uint32),
+ABI_VERSION = 6   # ZK_ABI_VERSION of include/zkstark_amd.h these declarations were written against; load() checks it
+
+
+class _Sized(C.Structure):
+    """A caller-allocated struct of the C ABI: its first field is struct_size = sizeof(the struct), which the library
+    checks before it reads or writes anything (include/zkstark_amd.h, "ABI version and caller-allocated structs")."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+    def fields(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k not in ("struct_size", "reserved")}
+
+
+class TranscriptInfo(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("alpha_raw", C.c_uint32 * 3), ("beta_raw", C.c_uint32 * 32), ("free_term", C.c_uint32),
                 ("query_raw", C.c_uint32), ("public_last", C.c_uint32), ("roots", (C.c_uint8 * 32) * 34)]
 
 
-class KernelStat(C.Structure):
-    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double), ("ops", C.c_double)]
+class KernelStat(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double), ("ops", C.c_double)]
 
 
 # zk_shard_transport: the two collectives of the sharded prover, supplied by the caller (tests: gloo-staged)
@@ -40,26 +54,34 @@ class ShardTransport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_to_all", ALL_TO_ALL_FN), ("all_gather", ALL_GATHER_FN)]
 
 
-class ShardOptions(C.Structure):
-    _fields_ = [("min_layer_log", C.c_uint32), ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32),
+def kernel_stat_array():
+    """One zk_kernel_stat per kernel class; out[0].struct_size is the array's stride."""
+    arr = (KernelStat * len(KERNEL_CLASSES))()
+    for e in arr:
+        e.struct_size = C.sizeof(KernelStat)
+    return arr
+
+
+class ShardOptions(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("min_layer_log", C.c_uint32), ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32),
                 ("force_collectives", C.c_int), ("no_root_board", C.c_int), ("plain_collectives", C.c_int),
                 ("single_build_stream", C.c_int), ("single_communicator", C.c_int), ("exchange_cp", C.c_int), ("timeout_s", C.c_double)]
 
 
-class ShardStats(C.Structure):
-    _fields_ = [("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
+class ShardStats(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
                 ("rccl_nranks", C.c_uint32), ("communicators", C.c_uint32), ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double),
                 ("exchange_ms", C.c_double), ("exposed_exchange_ms", C.c_double), ("tail_ms", C.c_double), ("selftest_ms", C.c_double), ("decommit_ms", C.c_double),
                 ("exchanges", C.c_uint32), ("selftest_ok", C.c_uint32)]
 
 
-class ChainProbe(C.Structure):
-    _fields_ = [("ns_per_hash_per_simd", C.c_double), ("clock_ghz", C.c_double), ("ms", C.c_double),
+class ChainProbe(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("ns_per_hash_per_simd", C.c_double), ("clock_ghz", C.c_double), ("ms", C.c_double),
                 ("waves_per_simd", C.c_uint32), ("launches", C.c_uint32), ("hashes", C.c_uint32), ("cus", C.c_uint32)]
 
 
-class ShardPlan(C.Structure):
-    _fields_ = [("world", C.c_uint32), ("log_world", C.c_uint32), ("sharded_layers", C.c_uint32), ("tail_rounds", C.c_uint32),
+class ShardPlan(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("log_world", C.c_uint32), ("sharded_layers", C.c_uint32), ("tail_rounds", C.c_uint32),
                 ("chunked_layers", C.c_uint32), ("chunked_mask", C.c_uint32), ("log_chunks", C.c_uint32), ("min_layer_log", C.c_uint32),
                 ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32), ("piece_log", C.c_uint32 * 32),
                 ("all_to_all_bytes", C.c_double), ("lde_commit_bytes", C.c_double), ("cp_from_f", C.c_uint32), ("reserved", C.c_uint32)]
@@ -75,6 +97,7 @@ SYMBOLS = {
     "zk_last_error": (_cp, []),
     "zk_version": (_cp, []),
     "zk_build_hash": (_cp, []),
+    "zk_abi_version": (_u32, []),
     "zk_host_hash_mode": (C.c_int, []),
     "zk_host_set_hash_mode": (C.c_int, [C.c_int]),
     "zk_field_add": (_u32, [_u32, _u32]),
@@ -228,6 +251,8 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
+    if lib.zk_abi_version() != ABI_VERSION:
+        raise ImportError(f"libzkstark_amd.so speaks ABI version {lib.zk_abi_version()}, zkstark_amd/_lib.py was written for {ABI_VERSION}")
     got = lib.zk_build_hash().decode()
     if want is not None and got != want and os.environ.get("ZK_ALLOW_STALE_LIB") != "1":
         why = f" and cannot be rebuilt here: {build_err}" if build_err is not None else " (python -m zkstark_amd.build)"

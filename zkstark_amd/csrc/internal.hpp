@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -29,6 +31,46 @@ const char* last_error();
         if (_e != hipSuccess)                                                                 \
             return ::zk::impl::fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// ---- ABI rule of include/zkstark_amd.h ("ABI version and caller-allocated structs") --------------------------------------
+// Size of each caller-allocated struct in ABI version 6, the first version that carries struct_size: the smallest size the
+// library accepts.  A struct only ever grows at its end, so these numbers never change.
+template <class T> struct AbiMin;
+template <> struct AbiMin<zk_transcript_info> { static constexpr uint32_t v = 1244; static constexpr const char* name = "zk_transcript_info"; };
+template <> struct AbiMin<zk_kernel_stat>     { static constexpr uint32_t v = 40;   static constexpr const char* name = "zk_kernel_stat"; };
+template <> struct AbiMin<zk_shard_options>   { static constexpr uint32_t v = 48;   static constexpr const char* name = "zk_shard_options"; };
+template <> struct AbiMin<zk_shard_stats>     { static constexpr uint32_t v = 112;  static constexpr const char* name = "zk_shard_stats"; };
+template <> struct AbiMin<zk_shard_plan_info> { static constexpr uint32_t v = 200;  static constexpr const char* name = "zk_shard_plan_info"; };
+template <> struct AbiMin<zk_chain_probe>     { static constexpr uint32_t v = 48;   static constexpr const char* name = "zk_chain_probe"; };
+// Bytes of *p the library may touch (min of the caller's and the library's size), or 0 after fail(): struct_size is 0, below
+// the version-6 size (a caller compiled against an older header, or one that never set it), or absurd.
+template <class T> inline size_t abi_bytes(const T* p, const char* who) {
+    static_assert(sizeof(T) >= AbiMin<T>::v && offsetof(T, struct_size) == 0, "a struct of the C ABI shrank or lost its size field");
+    const uint32_t n = p->struct_size;
+    if (n < AbiMin<T>::v || n > (1u << 16)) {
+        fail(ZK_ERR_INVALID, "%s: %s.struct_size is %u; the caller sets it to sizeof(%s) before the call (ZK_STRUCT_INIT): at least %u bytes "
+                             "(ABI version 6), %zu in this library (ABI version %u) -- was the caller compiled against another zkstark_amd.h?",
+             who, AbiMin<T>::name, n, AbiMin<T>::name, AbiMin<T>::v, sizeof(T), (unsigned)ZK_ABI_VERSION);
+        return 0;
+    }
+    return n < sizeof(T) ? n : sizeof(T);
+}
+// An output struct: the fields of `src` the caller's layout has room for; struct_size itself stays the caller's.
+template <class T> inline int abi_put(T* out, const T& src, const char* who) {
+    const size_t k = abi_bytes(out, who);
+    if (!k) return ZK_ERR_INVALID;
+    memcpy(reinterpret_cast<char*>(out) + sizeof(uint32_t), reinterpret_cast<const char*>(&src) + sizeof(uint32_t), k - sizeof(uint32_t));
+    return ZK_OK;
+}
+// An input struct: a full-size copy with the fields the caller does not know at 0 (= default).
+template <class T> inline int abi_get(const T* in, T* local, const char* who) {
+    const size_t k = abi_bytes(in, who);
+    if (!k) return ZK_ERR_INVALID;
+    memset(static_cast<void*>(local), 0, sizeof(T));
+    memcpy(static_cast<void*>(local), in, k);
+    local->struct_size = (uint32_t)sizeof(T);
+    return ZK_OK;
+}
 
 constexpr uint32_t kMaxQueries = 64;
 constexpr uint32_t kHostTopSingle = 8;                       // hand-over depth one thread reduces alone (255 nodes, ~8 us)

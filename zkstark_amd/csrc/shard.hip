@@ -875,9 +875,14 @@ int zk_shard_unique_id(uint8_t id_out[ZK_SHARD_ID_BYTES]) {
 // The layout of a sharded proof as a pure function of (world, sizes, options): which FRI layers stay distributed,
 // which of them are exchanged in chunks, and the bytes every rank sends to its peers.  zk_shard_create uses it, and so
 // does the test mirror (tests/sharded_mirror.py), so the two cannot drift apart.  No GPU needed.
-int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_options* opt, zk_shard_plan_info* out) {
-    if (!out) return fail(ZK_ERR_INVALID, "zk_shard_plan: out is null");
-    memset(out, 0, sizeof *out);
+int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_options* user_opt, zk_shard_plan_info* user_out) {
+    if (!user_out) return fail(ZK_ERR_INVALID, "zk_shard_plan: out is null");
+    if (!abi_bytes(user_out, "zk_shard_plan")) return ZK_ERR_INVALID;
+    zk_shard_options opt_local;
+    if (user_opt && abi_get(user_opt, &opt_local, "zk_shard_plan")) return ZK_ERR_INVALID;
+    const zk_shard_options* opt = user_opt ? &opt_local : nullptr;
+    zk_shard_plan_info plan_local{};
+    zk_shard_plan_info* const out = &plan_local;
     if (int rc = check_proof_size("zk_shard_plan", log_n, log_b)) return rc;
     if (world < 1 || world > 32) return fail(ZK_ERR_INVALID, "zk_shard_plan: world size %d out of range (1 .. 32)", world);
     uint32_t lg = 0;
@@ -931,7 +936,7 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
         out->all_to_all_bytes += sent;
         if (lid == 0) out->lde_commit_bytes = sent;
     }
-    return ZK_OK;
+    return abi_put(user_out, plan_local, "zk_shard_plan");
 }
 
 int zk_shard_destroy(zk_shard* s) {
@@ -988,10 +993,13 @@ int zk_shard_destroy(zk_shard* s) {
     return ZK_OK;
 }
 
-int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk_shard_transport* transport, const zk_shard_options* opt,
+int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk_shard_transport* transport, const zk_shard_options* user_opt,
                     uint32_t log_n, uint32_t log_b, zk_shard** out) {
     if (!out) return fail(ZK_ERR_INVALID, "zk_shard_create: out is null");
     *out = nullptr;
+    zk_shard_options opt_local;
+    if (user_opt && abi_get(user_opt, &opt_local, "zk_shard_create")) return ZK_ERR_INVALID;
+    const zk_shard_options* opt = user_opt ? &opt_local : nullptr;
     auto t0 = std::chrono::steady_clock::now();
     if (int rc = check_proof_size("zk_shard_create", log_n, log_b)) return rc;
     if (world < 1 || world > 32) return fail(ZK_ERR_INVALID, "zk_shard_create: world size %d out of range (1 .. 32)", world);
@@ -1031,6 +1039,7 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     } while (0)
     const uint32_t L = s->L, R = s->R;
     zk_shard_plan_info plan;
+    plan.struct_size = (uint32_t)sizeof plan;
     if ((rc = zk_shard_plan(world, log_n, log_b, opt, &plan))) return bail(rc);
     s->min_layer_log = plan.min_layer_log; s->min_chunk_log = plan.min_chunk_log; s->overlap_min_log = plan.overlap_min_log;
     const uint32_t ns = plan.sharded_layers;
@@ -1273,8 +1282,7 @@ int zk_shard_set_profiling(zk_shard* s, int on) {
 
 int zk_shard_last_transcript(const zk_shard* s, zk_transcript_info* out) {
     if (!s || !out) return fail(ZK_ERR_INVALID, "zk_shard_last_transcript: null argument");
-    *out = s->info;
-    return ZK_OK;
+    return abi_put(out, s->info, "zk_shard_last_transcript");
 }
 
 int zk_shard_layer_read(zk_shard* s, uint32_t layer, size_t offset, size_t count, uint32_t* out) {
@@ -1288,8 +1296,7 @@ int zk_shard_layer_read(zk_shard* s, uint32_t layer, size_t offset, size_t count
 
 int zk_shard_get_stats(const zk_shard* s, zk_shard_stats* out) {
     if (!s || !out) return fail(ZK_ERR_INVALID, "zk_shard_get_stats: null argument");
-    *out = s->stats;
-    return ZK_OK;
+    return abi_put(out, s->stats, "zk_shard_get_stats");
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 static const char kBuildTag[] = "zkstark_amd.build_hash=" ZK_SRC_HASH;
 
 extern "C" {
-const char* zk_version(void) { return "zkstark_amd 0.3 (gfx950)"; }
+const char* zk_version(void) { return "zkstark_amd 0.4 (gfx950)"; }
+uint32_t zk_abi_version(void) { return ZK_ABI_VERSION; }
 const char* zk_build_hash(void) { return kBuildTag + sizeof("zkstark_amd.build_hash=") - 1; }
 }

@@ -840,10 +840,23 @@ int zk_ctx_set_profiling(zk_ctx* c, uint32_t class_mask) {
     return ZK_OK;
 }
 
+// out[0].struct_size is the stride of the caller's array (include/zkstark_amd.h: zk_kernel_stat)
+static int put_kernel_stats(zk_kernel_stat* out, size_t count, const zk_kernel_stat* src, const char* who) {
+    if (!count) return ZK_OK;
+    const uint32_t stride = out[0].struct_size;
+    if (!abi_bytes(out, who)) return ZK_ERR_INVALID;
+    for (size_t i = 0; i < count && i < (size_t)K_COUNT; ++i) {
+        zk_kernel_stat* o = reinterpret_cast<zk_kernel_stat*>(reinterpret_cast<char*>(out) + i * stride);
+        o->struct_size = stride;
+        if (int rc = abi_put(o, src[i], who)) return rc;
+    }
+    return ZK_OK;
+}
+
 int zk_kernel_stats(zk_ctx* c, zk_kernel_stat* out, size_t count, int reset) {
     if (!c || (!out && count)) return fail(ZK_ERR_INVALID, "zk_kernel_stats: null argument");
     collect_kernel_stats(c);
-    for (size_t i = 0; i < count && i < (size_t)K_COUNT; ++i) out[i] = c->kstat[i];
+    if (int rc = put_kernel_stats(out, count, c->kstat, "zk_kernel_stats")) return rc;
     if (reset) for (int i = 0; i < K_COUNT; ++i) c->kstat[i] = zk_kernel_stat{};
     return ZK_OK;
 }
@@ -1031,8 +1044,7 @@ int zk_prove_many(zk_ctx* const* ctxs, size_t count, uint8_t* proofs_out, size_t
 
 int zk_last_transcript(const zk_ctx* c, zk_transcript_info* out) {
     if (!c || !out) return fail(ZK_ERR_INVALID, "zk_last_transcript: null argument");
-    *out = c->info;
-    return ZK_OK;
+    return abi_put(out, c->info, "zk_last_transcript");
 }
 
 int zk_verify_ex(const uint8_t* proof, size_t len, uint32_t log_n, uint32_t log_b, uint32_t public_last, int hash_kind) {
@@ -1186,7 +1198,7 @@ int zk_dev_kernel_stats(zk_kernel_stat* out, size_t count, int reset) {
         g_dev_prof.pool.push_back(r.a); g_dev_prof.pool.push_back(r.b);
     }
     g_dev_prof.recs.clear();
-    for (size_t i = 0; i < count && i < (size_t)K_COUNT; ++i) out[i] = g_dev_kstat[i];
+    if (int rc = put_kernel_stats(out, count, g_dev_kstat, "zk_dev_kernel_stats")) return rc;
     if (reset) for (int i = 0; i < K_COUNT; ++i) g_dev_kstat[i] = zk_kernel_stat{};
     return ZK_OK;
 }
@@ -1535,6 +1547,10 @@ int zk_merkle_build_host_ex(int device, const uint32_t* vals, size_t m, uint8_t*
 int zk_probe_hash_chain(int device, int hash_kind, uint32_t waves_per_simd, uint32_t hashes, uint32_t launches, zk_chain_probe* out) {
     if (!out || (hash_kind != ZK_HASH_SHA256 && hash_kind != ZK_HASH_FIELD) || waves_per_simd < 1 || waves_per_simd > 8 || !hashes || !launches)
         return fail(ZK_ERR_INVALID, "zk_probe_hash_chain: bad argument");
+    if (!abi_bytes(out, "zk_probe_hash_chain")) return ZK_ERR_INVALID;
+    zk_chain_probe* const user_out = out;
+    zk_chain_probe res{};
+    out = &res;
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -1571,7 +1587,7 @@ int zk_probe_hash_chain(int device, int hash_kind, uint32_t waves_per_simd, uint
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(d_out); (void)hipFree(d_rec);
-    return rc;
+    return rc ? rc : abi_put(user_out, res, "zk_probe_hash_chain");
 }
 
 // Test hook: the device's forms of the field hash against each other on `count` (rounded up to 256) pseudo-random and edge inputs.

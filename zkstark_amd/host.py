@@ -267,7 +267,7 @@ class Context:
         check(_lib.load().zk_ctx_set_profiling(self._h, mask))
 
     def kernel_stats(self, reset=True):
-        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()
+        arr = _lib.kernel_stat_array()
         check(_lib.load().zk_kernel_stats(self._h, arr, len(arr), int(reset)))
         return {name: {"launches": int(a.launches), "ms": a.ms, "bytes": a.bytes, "ops": a.ops}
                 for name, a in zip(_lib.KERNEL_CLASSES, arr)}
@@ -431,7 +431,7 @@ def shard_plan(world, log_n, log_blowup, min_layer_log=0, min_chunk_log=0, overl
     opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), 0, int(plain_collectives), 0, 0, int(exchange_cp), 0.0)
     pl = _lib.ShardPlan()
     check(_lib.load().zk_shard_plan(world, log_n, log_blowup, C.byref(opt), C.byref(pl)))
-    d = {k: getattr(pl, k) for k, _ in _lib.ShardPlan._fields_ if k != "piece_log"}
+    d = {k: v for k, v in pl.fields().items() if k != "piece_log"}
     d["piece_log"] = list(pl.piece_log)[:pl.sharded_layers + 1]
     return d
 
@@ -519,7 +519,7 @@ class ShardContext:
     def stats(self):
         st = _lib.ShardStats()
         check(_lib.load().zk_shard_get_stats(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in _lib.ShardStats._fields_}
+        return st.fields()
 
 
 def generate_proof(channel, log_n=10, log_blowup=3, a0=1, a1=3141592, ctx=None):
