@@ -351,6 +351,12 @@ typedef struct zk_shard_options {   /* zero = default (struct_size excepted) */
                                    cp over a rank's block is recomputed from the block of f the rank received for the
                                    commitment of f, inside the leaf hashing -- no exchange for cp (zk_shard_plan_info.cp_from_f) */
     double timeout_s;           /* bound of every host-side wait on a peer; 0 = environment ZK_SHARD_TIMEOUT_S, else 120 s */
+    int peer_copy;              /* transport == NULL: instead of RCCL, the built-in PEER-COPY transport (csrc/peer.hpp): the ranks of one
+                                   node publish IPC handles of their send buffers on a shared-memory page and every rank pulls its
+                                   pieces with device-to-device copies.  Host-synchronous (implies plain_collectives); `id` is any 128
+                                   bytes shared by the ranks.  The rung below "RCCL, plain collectives": for a node where no
+                                   communicator can be formed (bench.py --gpus N falls back to it) */
+    int reserved;
 } zk_shard_options;
 typedef struct zk_shard_stats {
     uint32_t struct_size;       /* sizeof(zk_shard_stats), set by the caller (see "ABI version" above) */
@@ -378,6 +384,8 @@ typedef struct zk_shard_stats {
     double decommit_ms;         /* host time of the decommitment (prover.rs:266-289), all queries, profiling on */
     uint32_t exchanges;         /* collectives timed (profiling on) */
     uint32_t selftest_ok;       /* 1: zk_shard_create's known-pattern all-to-all + all-gather arrived in the right places */
+    uint32_t peer_copy;         /* 1: the built-in peer-copy transport (zk_shard_options.peer_copy) */
+    uint32_t reserved;
 } zk_shard_stats;
 /* The layout of a sharded proof, as a pure function of its arguments (no GPU, no communication): what
  * zk_shard_create will do.  Layer ids: 0 = f_eval, 1 + r = FRI layer r. */

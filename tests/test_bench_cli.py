@@ -24,8 +24,9 @@ def test_bench_gpus_n_spawns_ranks_and_needs_n_gpus():
 
 
 def _load_bench():
+    """The N > 1 side of the benchmark (launcher, supervisors, generations, ladder): bench_multi.py since round 6."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("zk_bench_module", os.path.join(ROOT, "bench.py"))
+    spec = importlib.util.spec_from_file_location("zk_bench_multi_module", os.path.join(ROOT, "bench_multi.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -128,11 +129,12 @@ def test_bench_n2_rehearsal_on_one_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("env_extra,want_transport", [
     ({"ZK_BENCH_TRANSPORT": "torch"}, "torch"),                      # torch.distributed's RCCL communicator on device pointers
-    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "1"}, "torch"),            # the native transport "fails": the line says so and falls back
-    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "id"}, "torch"),           # rank 0 cannot even draw the unique id: every rank learns it together
+    ({"ZK_BENCH_TRANSPORT": "peer"}, "peer"),                        # the library's peer-copy transport (no RCCL; round 6)
+    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "1"}, "peer"),             # the native transport "fails" twice: the line says so and falls back
+    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "id"}, "peer"),            # rank 0 cannot even draw the unique id: every rank learns it together
     # the native transport HANGS (as ncclCommInitRank can): the worker's watchdog ends it, the supervisor starts a fresh
-    # worker on the next rung, twice; the line comes from the third worker
-    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "hang", "ZK_BENCH_RUNG_BUDGET_S": "10,10,60"}, "torch"),
+    # worker on the next rung, twice; the line comes from the third worker, on the rung that needs no RCCL
+    ({"ZK_BENCH_SIMULATE_NATIVE_FAILURE": "hang", "ZK_BENCH_RUNG_BUDGET_S": "10,10,60,60"}, "peer"),
     ({}, "native"),
 ])
 def test_bench_sharded_transports_one_rank(env_extra, want_transport):
@@ -158,6 +160,7 @@ def test_bench_sharded_transports_one_rank(env_extra, want_transport):
         assert k in rec["shard"], k
     assert rec["shard"]["per_rank"][0]["rank"] == 0 and rec["shard"]["per_rank"][0]["exchanges"] > 0
     assert rec["shard"]["native_rccl"] == (1 if want_transport == "native" else 0)
+    assert rec["shard"]["peer_copy"] == (1 if want_transport == "peer" else 0)
     if want_transport == "native":
         assert rec["shard"]["rccl_nranks"] == 1
 
@@ -194,3 +197,58 @@ def test_bench_strong_scaling_and_exact_config4_rehearsal():
     c4 = rec["config4_2e26"]
     assert "2^26" in c4["workload"] and c4["root_stable"] is True and c4["root_matches_golden"] is True
     assert c4["all_to_all_bytes_per_rank"] == 4.0 * (1 << 26) / 2 / 2
+
+
+def test_bench_plan_only_needs_no_gpu():
+    """`bench.py --plan-only`: zk_shard_plan for N = 2, 4, 8 at the weak and the strong shape, with the estimated per-rank critical
+    path, as one JSON document -- the prediction the one multi-GPU run is read against.  No GPU, no torch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan-only"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    doc = json.loads(out.stdout)
+    runs = {(r["world"], r["shape"], "plain" in r["transport"]): r for r in doc["runs"]}
+    assert set(w for w, _, _ in runs) == {2, 4, 8} and len(runs) == 12
+    r = runs[(8, "weak", False)]
+    assert r["domain_log2"] == 27 and r["plan"]["sharded_layers"] == 8 and r["plan"]["cp_from_f"] == 1
+    N = 1 << 27
+    words = N + sum(N >> rho for rho in range(1, 8))                  # f and FRI layers 1 .. 7; cp comes from the block of f
+    assert r["plan"]["all_to_all_bytes"] == 4.0 * words / 8 * 7 / 8 and abs(r["bytes_per_element_on_the_links"] - 4.0 * words * 7 / 8 / N) < 1e-9
+    assert runs[(8, "weak", True)]["plan"]["chunked_layers"] == 0 and runs[(8, "strong", False)]["domain_log2"] == 24
+    for r in doc["runs"]:
+        assert "ESTIMATE" in " ".join(r["estimate"].keys())             # every timing figure says what it is
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plan-only"], capture_output=True, text=True, timeout=120, env=env)
+    assert {r["world"] for r in json.loads(one.stdout)["runs"]} == {4}
+
+
+def test_bench_is_three_files():
+    """the entry point under 600 lines; the N > 1 machinery and the secondary legs in their own modules."""
+    n = lambda f: sum(1 for _ in open(os.path.join(ROOT, f)))
+    assert n("bench.py") < 600 and n("bench_multi.py") > 100 and n("bench_legs.py") > 100
+    main = open(os.path.join(ROOT, "bench.py")).read()
+    assert "def supervise" not in main and "def spawn_ranks" not in main and "import bench_multi" in main and "import bench_legs" in main
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_extra,want_note", [
+    ({"ZK_BENCH_TRANSPORT": "peer"}, False),
+    # the whole ladder with two ranks that SHARE the one GPU: RCCL cannot form a communicator of two ranks on one device (the
+    # stand-in for "RCCL does not come up on the driver's node"), the run falls through to the rung that needs no RCCL
+    ({"ZK_BENCH_RUNG_BUDGET_S": "40,30,60,60"}, True),
+])
+def test_bench_two_ranks_sharing_the_gpu_on_the_peer_copy_rung(env_extra, want_note):
+    """Row e's fall-back below RCCL, end to end: launcher, supervisors, gloo control plane, zk_shard_* over the library's
+    peer-copy transport (IPC handles between the two processes, device-to-device pulls), headline + strong leg + parity."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ZK_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "17"],
+                         capture_output=True, text=True, timeout=560, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["transport"] == "peer" and rec["parity_checked"] is True and rec["shard"]["ranks_agree"] is True
+    assert rec["shard"]["peer_copy"] == 1 and rec["shard"]["native_rccl"] == 0 and rec["shard"]["chunked_layers"] == 0
+    assert (rec["transport_note"] is not None) == want_note
+    st = rec["strong_2e20"]
+    assert st["parity"]["equal"] is True and st["ranks_agree"] is True and st["shard"]["peer_copy"] == 1
+    assert rec["lde_commit_sharded"]["root_stable"] is True

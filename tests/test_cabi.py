@@ -384,11 +384,19 @@ def test_stale_or_unsized_structs_are_refused(zk):
             assert "zk_shard_plan_info.struct_size" in msg and str(bad) in msg and str(C.sizeof(_lib.ShardPlan)) in msg, msg
             assert pl.world == 777                                     # nothing was written
         # input struct: the same rule
-        for bad in (0, C.sizeof(_lib.ShardOptions) - 8):
+        for bad in (0, 21, 40):                                        # never set; round 5's first field (min_layer_log); too small
             opt = _lib.ShardOptions()
             opt.struct_size = bad
             assert plan_fn(2, 22, 3, C.byref(opt), C.byref(_lib.ShardPlan())) == -1
             assert "zk_shard_options.struct_size" in lib.zk_last_error().decode()
+        # a caller compiled against the FIRST version-6 layout (48 bytes, before `peer_copy` was appended): accepted, and what lies
+        # behind its struct is not read (here: a set peer_copy field, which would force plain collectives)
+        opt = _lib.ShardOptions(peer_copy=1)
+        assert C.sizeof(opt) > 48
+        pl = _lib.ShardPlan()
+        assert plan_fn(8, 24, 3, C.byref(opt), C.byref(pl)) == 0 and pl.overlap_min_log == 99
+        opt.struct_size = 48
+        assert plan_fn(8, 24, 3, C.byref(opt), C.byref(pl)) == 0 and pl.overlap_min_log == 21
         # a larger struct from a newer caller: fields the library knows are filled, the tail is left alone
 
         class BiggerPlan(C.Structure):

@@ -394,6 +394,46 @@ def test_merkle_commit_pending_tree_top(zk, orc):
         p = ctx.prove()
         assert p.data == want.proof and p.state == want.state
         assert ctx.merkle_node(0, 3) == bytes(n0[3])           # the proof rebuilt tree 0 from the same trace
+        # the shape of bench.py's configs[1] loop -- lde; commit(0) over and over, the pending top of the previous
+        # iteration dropped every time, an lde in between -- then the first reader must still see a whole tree; and the loop as
+        # the benchmark runs it since round 6 (the top's copy ordered on the stream every iteration: Context.stream)
+        for settle in (False, True):
+            for _ in range(4):
+                ctx.lde()
+                rr = ctx.merkle_commit(0)
+                if settle:
+                    ctx.stream
+            assert rr == bytes(n0[0])
+            ctx.lde()                                          # a transform between the commitment and its first reader
+            assert ctx.merkle_path(0, 4097) == [bytes(x) for x in orc.merkle_trace(n0, 4097)]
+            for idx in (0, 1, 127, 254, 255, 256, 510, 511):   # both sides of the hand-over depth
+                assert ctx.merkle_node(0, idx) == bytes(n0[idx]), idx
+
+
+def test_caller_allocated_structs_carry_their_size(zk):
+    """include/zkstark_amd.h, "ABI version and caller-allocated structs", on the entry points that need a context: a
+    zk_kernel_stat array or a zk_transcript_info whose struct_size is unset (a caller compiled against round 5's header) is
+    refused with ZK_ERR_INVALID before anything is written; sized ones work (every other test goes through them)."""
+    import ctypes as C
+    from zkstark_amd import _lib
+    lib = _lib.load()
+    with zk.Context(10, 3) as ctx:
+        ctx.prove(zk.trace_fibsq(1023))
+        arr = (_lib.KernelStat * len(_lib.KERNEL_CLASSES))()           # ctypes arrays do not run __init__: struct_size = 0
+        assert lib.zk_kernel_stats(ctx._h, arr, len(arr), 0) == -1 and "zk_kernel_stat.struct_size is 0" in lib.zk_last_error().decode()
+        assert lib.zk_dev_kernel_stats(arr, len(arr), 0) == -1
+        info = _lib.TranscriptInfo()
+        info.struct_size = C.sizeof(info) - 4
+        info.free_term = 4242
+        assert lib.zk_last_transcript(ctx._h, C.byref(info)) == -1 and info.free_term == 4242
+        assert "zk_transcript_info.struct_size" in lib.zk_last_error().decode()
+        good = ctx.last_transcript()
+        assert good.struct_size == C.sizeof(good) and good.public_last == 2338775057
+        pr = _lib.ChainProbe()
+        pr.struct_size = 0
+        assert lib.zk_probe_hash_chain(0, 0, 4, 1, 1, C.byref(pr)) == -1
+        st = ctx.kernel_stats()
+        assert set(st) == set(_lib.KERNEL_CLASSES)
 
 
 @pytest.mark.parametrize("q", [2, 7, 64])

@@ -182,8 +182,10 @@ def _worker(rank, world, port, log_n, log_b, opts, q, mode, uid):
         import zkstark_amd as zk
         from sharded_testlib import gloo_transport
         torch.cuda.set_device(0)
-        tp = gloo_transport()
-        with zk.ShardContext(log_n, log_b, rank, world, uid, transport=tp, **opts) as sp:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the caller's transport (gloo, host-staged), or -- peer_copy -- the library's own peer copies through IPC handles
+        tp = None if opts.get("peer_copy") else gloo_transport()
+        with zk.ShardContext(log_n, log_b, rank, world, uid, transport=tp, timeout_s=30.0, **opts) as sp:
             sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
             if mode == "prove":
                 proof = sp.prove()
@@ -277,6 +279,44 @@ def test_shard_multirank_one_gpu_matches_oracle(orc, world, log_n, log_b, opts):
         pl = zk.shard_plan(world, log_n, log_b, **{k: v for k, v in opts.items() if k in ("min_layer_log", "min_chunk_log", "overlap_min_log", "exchange_cp")})
         assert pl["cp_from_f"] == (0 if opts.get("exchange_cp") else 1)
         assert (st["sharded_layers"], st["chunked_layers"], st["all_to_all_bytes"]) == (pl["sharded_layers"], pl["chunked_layers"], pl["all_to_all_bytes"])
+
+
+@pytest.mark.parametrize("world,log_n,log_b,opts", [
+    (2, 12, 3, dict(min_layer_log=1, min_chunk_log=6, peer_copy=True)),
+    (4, 14, 3, dict(min_layer_log=1, min_chunk_log=6, overlap_min_log=8, peer_copy=True)),     # overlap_min_log is overridden: nothing in chunks
+    (2, 18, 3, dict(peer_copy=True)),                                                             # production thresholds
+])
+def test_shard_peer_copy_transport_matches_oracle(orc, world, log_n, log_b, opts):
+    """The built-in PEER-COPY transport (zk_shard_options.peer_copy, csrc/peer.hpp: IPC handles on a shared page, device-to-device
+    pulls, no RCCL and no caller transport) with 2 / 4 processes sharing the GPU: every rank's proof, state and roots equal the
+    oracle's; plain collectives only (roots by all-gather), the byte counters as planned."""
+    want = orc.prove(log_n, log_b, want_vectors=False, want_roots=True)
+    out = _run(world, log_n, log_b, opts, "prove")
+    import zkstark_amd as zk
+    pl = zk.shard_plan(world, log_n, log_b, **{k: v for k, v in opts.items() if k in ("min_layer_log", "min_chunk_log", "overlap_min_log", "peer_copy")})
+    assert pl["chunked_layers"] == 0 and pl["overlap_min_log"] == 99
+    for rank, data, state, roots, st in out:
+        assert data == want.proof and state == want.state, f"rank {rank}"
+        assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
+        assert st["peer_copy"] == 1 and st["native_rccl"] == 0 and st["root_board"] == 0 and st["chunked_layers"] == 0 and st["selftest_ok"] == 1
+        assert (st["sharded_layers"], st["all_to_all_bytes"]) == (pl["sharded_layers"], pl["all_to_all_bytes"])
+
+
+def test_shard_peer_copy_one_rank_and_a_peer_that_never_comes(zk, orc):
+    """One rank with the collectives forced goes through the peer-copy code with itself as the only peer; a rank whose peer never
+    arrives gets an error naming what it waited for within timeout_s (not a hang)."""
+    want = orc.prove(12, 3, want_vectors=False)
+    uid = os.urandom(128)
+    with zk.ShardContext(12, 3, 0, 1, uid, force_collectives=True, peer_copy=True, min_layer_log=1, min_chunk_log=4) as sp:
+        sp.trace_upload(zk.trace_fibsq((1 << 12) - 1))
+        proof = sp.prove()
+        assert sp.stats()["peer_copy"] == 1
+    assert proof.data == want.proof and proof.state == want.state
+    import time
+    t0 = time.time()
+    with pytest.raises(zk.ZkError) as e:
+        zk.ShardContext(12, 3, 0, 2, os.urandom(128), peer_copy=True, timeout_s=2.0, min_layer_log=1, min_chunk_log=4)   # rank 1 does not exist
+    assert "peer-copy transport" in str(e.value) and time.time() - t0 < 20
 
 
 def test_shard_two_ranks_production_sizes_2e25(orc):

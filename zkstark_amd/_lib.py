@@ -65,14 +65,15 @@ def kernel_stat_array():
 class ShardOptions(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("min_layer_log", C.c_uint32), ("min_chunk_log", C.c_uint32), ("overlap_min_log", C.c_uint32),
                 ("force_collectives", C.c_int), ("no_root_board", C.c_int), ("plain_collectives", C.c_int),
-                ("single_build_stream", C.c_int), ("single_communicator", C.c_int), ("exchange_cp", C.c_int), ("timeout_s", C.c_double)]
+                ("single_build_stream", C.c_int), ("single_communicator", C.c_int), ("exchange_cp", C.c_int), ("timeout_s", C.c_double),
+                ("peer_copy", C.c_int), ("reserved", C.c_int)]
 
 
 class ShardStats(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("sharded_layers", C.c_uint32), ("root_board", C.c_uint32), ("chunked_layers", C.c_uint32), ("native_rccl", C.c_uint32),
                 ("rccl_nranks", C.c_uint32), ("communicators", C.c_uint32), ("sent_bytes", C.c_double), ("all_to_all_bytes", C.c_double), ("setup_ms", C.c_double), ("device_bytes", C.c_double),
                 ("exchange_ms", C.c_double), ("exposed_exchange_ms", C.c_double), ("tail_ms", C.c_double), ("selftest_ms", C.c_double), ("decommit_ms", C.c_double),
-                ("exchanges", C.c_uint32), ("selftest_ok", C.c_uint32)]
+                ("exchanges", C.c_uint32), ("selftest_ok", C.c_uint32), ("peer_copy", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ChainProbe(_Sized):

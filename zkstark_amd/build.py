@@ -22,7 +22,7 @@ LIB = os.path.join(HERE, "libzkstark_amd.so")
 HASHFILE = LIB + ".hash"
 SOURCES = ["kernels.hip", "ntt_fast.hip", "domain.hip", "zkstark.hip", "batch.hip", "shard.hip", "host_sha.cpp", "version.cpp"]
 HEADERS = ["field.hpp", "sha256.hpp", "sha256_quad.hpp", "fieldhash.hpp", "fieldhash_f64.hpp", "kernels.hpp", "transcript.hpp", "host_sha.hpp", "internal.hpp", "pool.hpp",
-           "shard.hpp", "board.hpp", os.path.join("..", "..", "include", "zkstark_amd.h")]
+           "shard.hpp", "board.hpp", "peer.hpp", os.path.join("..", "..", "include", "zkstark_amd.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
 # build-time experiments (e.g. ZK_BUILD_DEFS="-DZK_MONT_VARIANT=4"): part of the flags, hence of the source hash

@@ -43,6 +43,7 @@ struct zk_batch {
     uint32_t* h_mail = nullptr;       // pinned, mapped (MailArgs layout)
     uint32_t* d_mail = nullptr;
     uint32_t* d_counter = nullptr;
+    bool counters_dirty = false;
     uint32_t mail_seq = 0;
     uint64_t *d_goff = nullptr, *h_goff = nullptr;
     uint32_t *d_gout = nullptr, *h_gout = nullptr;
@@ -86,11 +87,16 @@ uint32_t bextra(const zk_batch* b, uint32_t log_m) {
 }
 MailArgs bmail(zk_batch* b, uint32_t log_m) {
     MailArgs m;
+    if (b->counters_dirty) { (void)hipMemsetAsync(b->d_counter, 0, 64, b->stream); b->counters_dirty = false; }
     m.mailbox = b->d_mail; m.seq = ++b->mail_seq; m.counter = b->d_counter; m.top = b->lb + bextra(b, log_m);
     return m;
 }
 // the batch's roots of the last commit launch: [batch][8] state words in the mailbox
-int bwait_roots(zk_batch* b) { return wait_flag(b->h_mail, b->mail_seq, b->stream); }
+int bwait_roots(zk_batch* b) {
+    const int rc = wait_flag(b->h_mail, b->mail_seq, b->stream);
+    if (rc) b->counters_dirty = true;                     // see zk_ctx::counters_dirty (zkstark.hip)
+    return rc;
+}
 // After bwait_roots: hashes the `extra` host levels of every proof's tree `tree` and returns where the roots
 // are ([batch][8] state words): the mailbox itself when the device went all the way.
 const uint32_t* bfinish_roots(zk_batch* b, uint32_t tree, uint32_t log_m) {

@@ -101,15 +101,18 @@ struct RootBoard {
     }
     // Blob exchange number seq = 1, 2, ... (its own sequence, the same on every rank).  blob_post publishes this rank's
     // `words` words (<= blob_words); blob_wait returns rank q's blob of that exchange in place (valid until this rank has
-    // posted exchange seq + 2).
+    // posted exchange seq + 2: a caller that keeps the data beyond its next blob_post copies it out, as shard.hip's decommit does).
     void blob_post(uint64_t seq, const uint32_t* data, size_t words) {
         uint32_t* my = blob(seq, rank);
         memcpy(my, data, words * sizeof(uint32_t));
         __atomic_store_n(reinterpret_cast<uint64_t*>(my + blob_words), seq, __ATOMIC_RELEASE);   // after the data
     }
-    Status blob_wait(uint64_t seq, int q, const uint32_t** data, double timeout_s = 120.0) {
+    // t0: when the caller started waiting for THIS exchange (one clock for all peers, as exchange() has: G waits of timeout_s
+    // each would add up to G * timeout_s)
+    Status blob_wait(uint64_t seq, int q, const uint32_t** data, double timeout_s = 120.0,
+                     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now()) {
         const uint32_t* src = blob(seq, q);
-        const Status st = wait_seq(reinterpret_cast<const uint64_t*>(src + blob_words), seq, q, std::chrono::steady_clock::now(), timeout_s);
+        const Status st = wait_seq(reinterpret_cast<const uint64_t*>(src + blob_words), seq, q, t0, timeout_s);
         if (st == kOk) *data = src;
         return st;
     }

@@ -10,11 +10,20 @@
 //   mulmod(a, b):  h = a * b (rounded), l = fma(a, b, -h)        a * b = h + l exactly, whatever the magnitudes
 //                  q = rint(h / P), r = fma(-q, P, h) + l         r = a b (mod P), |r| <= 0.75 P + 2^28
 //     exact while |h| < 2^50 P (q is then an integer within 3/4 of h / P, so h - q P is an integer below 2^32 and the
-//     fused multiply-add returns it exactly); here |a b| < 2^76.
+//     fused multiply-add returns it exactly); every product but one kind has |a b| < 2^76.
+//     The exception is the FIRST product of the S-box of s_0 in the partial rounds: s_0 <- sum - 2 s_0 is never
+//     reduced by the internal layer, so that S-box squares an input of up to 2^41.9 (sum <= 2^41.8, below): h < 2^83.8,
+//     h / P < 2^52.2.  There the quotient is no longer within 3/4: h * (1 / P) carries a relative error of 2^-52 (the rounded
+//     reciprocal and the rounded product), an absolute one of <= 1.15, so q = rint(..) is an integer within 1.65 of h / P; it is
+//     still exact as a double (< 2^53), h (a multiple of 2^31) - q P is an integer below 1.65 P < 2^32.4, the fused multiply-add
+//     returns it exactly, and l = fma(a, a, -h) is an integer below 2^30.8: x2 = x^2 (mod P) EXACTLY, with |x2| < 2^32.6 instead
+//     of < 0.84 P.  The two products that follow are in the ordinary regime (x2^2 < 2^65.2; x4 x < 2^31.3 * 2^41.9 = 2^73.2), so
+//     the S-box output is <= 0.75 P + 2^19.2 like every other.  zk_probe_fieldhash_forms feeds the S-box directed inputs of
+//     +-2^37.8 ... +-2^42 and multiples of P next to them, against x^5 in plain integer arithmetic (tests/test_fieldhash.py).
 //   The state is kept as SIGNED representatives; magnitudes (bounds, not estimates):
 //     S-box output            <= 0.75 P + 2^28 < 0.84 P
 //     external layer output   <= 5 * 16 * 0.84 P < 2^37.7           (M4 row sums <= 16, then + the four blocks' sum)
-//     S-box input             <  2^37.8, its square < 2^75.6
+//     S-box input             <  2^37.8 (full rounds), < 2^41.9 (s_0 in the partial rounds: see above)
 //     internal layer          d_i s_i + sum <= 2^14 * 2^37.7 + 2^41.7 < 2^51.7 on entry (exact); s_1 .. s_15 are reduced to
 //                             [-P/2, P/2] every second round, s_12 .. s_15 every round (fh64_internal); s_0 by its S-box
 //   Digest words are canonical residues again: reduce, add P if negative, convert.

@@ -733,6 +733,20 @@ __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
     p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
 }
 
+// ---- diagnostic build: where the time of a latency launch goes (ZK_BUILD_DEFS="-DZK_WG_TRACE=1"; tools/wg_trace.py) ----------
+// Thread 0 of workgroup 0 stamps the 100 MHz constant clock (s_memrealtime: one time base for every compute unit) at entry,
+// after the inputs are in LDS, and after every level; the workgroup that carries on (continuation) and the one that posts to the
+// host stamp their steps into the same record.  Records are dumped to $ZK_WG_TRACE_FILE when a context is destroyed.  Not part
+// of a product build: the stamps cost a scalar memory-time read and a store per level.
+#ifdef ZK_WG_TRACE
+constexpr uint32_t kWgTraceSlots = 48, kWgTraceLaunches = 8192;
+__device__ unsigned long long g_wg_trace[kWgTraceLaunches][kWgTraceSlots];
+__device__ unsigned int g_wg_trace_n, g_wg_trace_cur;
+#define WG_STAMP(slot) do { if (threadIdx.x == 0 && wg_rec < kWgTraceLaunches && (slot) < kWgTraceSlots) g_wg_trace[wg_rec][(slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WG_STAMP(slot) do { } while (0)
+#endif
+
 // When the launch reaches the hand-over depth (MailArgs.top; 0 = the root) and a mailbox is given, the
 // digests of that depth are also written to host-mapped memory followed by a sequence number, so the
 // host prover can poll for them instead of paying a blit kernel + stream synchronisation per commitment.
@@ -751,6 +765,19 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     const size_t in_base = ((size_t)1 << depth_in) - 1;
     QuadLane ql;
     if (HASH == 0) ql = quad_lane(tid);
+#ifdef ZK_WG_TRACE
+    uint32_t wg_rec = 0xffffffffu;                                // record of this launch; only workgroup 0 knows it until the hand-over
+    if (blockIdx.x == 0 && tid == 0) {
+        wg_rec = atomicAdd(&g_wg_trace_n, 1u);
+        __hip_atomic_store(&g_wg_trace_cur, wg_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wg_rec < kWgTraceLaunches) {
+            for (uint32_t i = 0; i < kWgTraceSlots; ++i) g_wg_trace[wg_rec][i] = 0;
+            g_wg_trace[wg_rec][0] = (unsigned long long)depth_in | ((unsigned long long)j << 8) | ((unsigned long long)j2 << 16) | ((unsigned long long)(LEAF ? 1 : 0) << 24) |
+                                    ((unsigned long long)HASH << 25) | ((unsigned long long)(mail.mailbox ? mail.top + 1 : 0) << 26) | ((unsigned long long)gridDim.x << 32);
+        }
+    }
+    WG_STAMP(1);
+#endif
     // a thread takes up to 2^kWgMaxLog / kWgThreads = 4 inputs: every read is issued before the first one is used (one
     // load latency per launch instead of one per input; this phase is a chain of latencies)
     constexpr uint32_t kPer = (1u << kWgMaxLog) / kWgThreads;
@@ -780,12 +807,14 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     // they are posted to the host: make every wave's stores visible device-wide, not only the posting wave's
     if (LEAF && mail.dump_src) __threadfence();
     __syncthreads();
+    WG_STAMP(2);
 #pragma unroll 1
   for (uint32_t phase = 0;; ++phase) {
 #pragma unroll 1
     for (uint32_t t = 1; t <= lv; ++t) {
         const uint32_t w = cnt >> t;                              // nodes of this level in the workgroup
         const size_t out_base = (((size_t)1 << (d_in - t)) - 1) + (first >> t);
+        WG_STAMP((phase ? 24u : 2u) + t - 1u);                   // start of level t = end of level t - 1
         if (HASH == 0 && w <= 64) {
             // Latency-bound level of <= 64 nodes per workgroup: one SHA-256 per FOUR lanes (sha256_quad.hpp: ~1 700
             // instructions on the wave instead of 2 293, no exchange inside the hash), 16 hashes per wave, the waves of
@@ -933,6 +962,7 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         if (a1) { lds_store(&lvl[2 * (tid + kWgThreads)], d1); store_digest(nodes, out_base + tid + kWgThreads, d1); }
         __syncthreads();
     }
+    WG_STAMP((phase ? 24u : 2u) + lv);                           // end of the last level of this phase
     if (phase == 1 || j2 == 0) break;
     // Continuation.  Every workgroup has written its node of depth depth_in - j (the barrier that ends a level has drained
     // the stores of all its waves); an agent-scope release / acquire on a counter tells the one that arrives last, and that
@@ -955,6 +985,10 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     }
     __syncthreads();
     if (!go_on) return;                                            // workgroup-uniform
+#ifdef ZK_WG_TRACE
+    if (tid == 0) wg_rec = __hip_atomic_load(&g_wg_trace_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroup 0 wrote it before it reached the counter
+    WG_STAMP(15);
+#endif
     d_in = depth_in - j; lv = j2; cnt = gridDim.x; first = 0;
     {
         const size_t base2 = ((size_t)1 << d_in) - 1;
@@ -967,6 +1001,7 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
             if (tid + u * kWgThreads < cnt) lds_store(&lvl[2 * (tid + u * kWgThreads)], dd[u]);
     }
     __syncthreads();
+    WG_STAMP(16);
   }
     // The launch that reaches depth mail.top posts its 2^top digests (and, on request, the layer values) to the
     // host: small PCIe writes are slow, so the workgroup that finishes last copies everything with wide stores.
@@ -983,6 +1018,10 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         }
         __syncthreads();
         if (is_last) {
+#ifdef ZK_WG_TRACE
+            if (tid == 0 && wg_rec == 0xffffffffu) wg_rec = __hip_atomic_load(&g_wg_trace_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            WG_STAMP(40);
+#endif
             const uint4* sq = reinterpret_cast<const uint4*>(nodes + (((size_t)1 << mail.top) - 1) * 8);
             uint4* dq = reinterpret_cast<uint4*>(mail.mailbox + kMailDigests);
             for (uint32_t i = tid; i < (2u << mail.top); i += kWgThreads) dq[i] = sq[i];
@@ -993,10 +1032,39 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
             }
             __threadfence_system();
             __syncthreads();
+            WG_STAMP(41);
             if (tid == 0) __hip_atomic_store(&mail.mailbox[0], mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            WG_STAMP(42);
         }
     }
 }
+
+#ifdef ZK_WG_TRACE
+// Appends the records collected so far to $ZK_WG_TRACE_FILE (one line per latency launch) and clears them; called when a context
+// is destroyed.  meta: depth_in, j, j2, leaf, hash, hand-over depth + 1 (0: no mailbox), workgroups; then the stamps in 10 ns ticks
+// relative to the launch's first stamp (0 = not reached).
+void dump_wg_trace() {
+    const char* path = getenv("ZK_WG_TRACE_FILE");
+    unsigned int n = 0;
+    if (!path || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wg_trace_n), sizeof n) != hipSuccess || !n) return;
+    if (n > kWgTraceLaunches) n = kWgTraceLaunches;
+    std::vector<unsigned long long> rec((size_t)n * kWgTraceSlots);
+    if (hipMemcpyFromSymbol(rec.data(), HIP_SYMBOL(g_wg_trace), rec.size() * 8) != hipSuccess) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    for (unsigned int r = 0; r < n; ++r) {
+        const unsigned long long* x = &rec[(size_t)r * kWgTraceSlots];
+        const unsigned long long m = x[0];
+        fprintf(f, "wg depth_in=%llu j=%llu j2=%llu leaf=%llu hash=%llu top=%lld wgs=%llu abs0=%llu :", m & 255, (m >> 8) & 255, (m >> 16) & 255, (m >> 24) & 1, (m >> 25) & 1,
+                (long long)((m >> 26) & 63) - 1, m >> 32, x[1]);
+        for (uint32_t i = 1; i < kWgTraceSlots; ++i) fprintf(f, " %lld", x[i] ? (long long)(x[i] - x[1]) : -1LL);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    const unsigned int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_n), &zero, sizeof zero);
+}
+#endif
 
 static double merkle_bytes(bool leaf, uint32_t depth, uint32_t k) {
     // inputs read once (4 B values or 32 B digests), every produced digest written once
@@ -1374,6 +1442,42 @@ __global__ __launch_bounds__(256) void fieldhash_forms_kernel(uint32_t seed, uin
     for (int i = 0; i < 8; ++i) {
         const uint32_t want = __shfl(b.w[i], (int)(threadIdx.x & ~15u) & 63, 64);
         if (g == (uint32_t)i && (row != want || row64 != want)) ok = false;
+    }
+    {   // Directed inputs of the double-precision S-box (fieldhash_f64.hpp: the s_0 path of the partial rounds squares up to 2^41.9,
+        // where the quotient of the first product needs all 53 bits): integers of magnitude 2^37.8 ... 2^42 and multiples of P next to
+        // them, both signs, against x^5 (mod P) in plain integer arithmetic.
+        const double mags[6] = {236118324143.0 /* 2^37.78 */, 3829546563953.0 /* 2^41.8 */, 4104397301943.0 /* 2^41.9 */, 4398046511103.0 /* 2^42 - 1 */,
+                                (double)P * 1365.0, (double)P * 1024.0};
+        const uint32_t k = t % 6u;
+        double xd = mags[k] + (double)(int)((rnd() & 0xFFFFu)) - 32768.0 + (k >= 4 ? (double)(rnd() % 3u) - 1.0 : 0.0);
+        if (t & 8u) xd = -xd;
+        const long long xi = (long long)xd;                           // exact: |x| < 2^43
+        const uint64_t res = (uint64_t)(((xi % (long long)P) + (long long)P) % (long long)P);
+        const uint64_t x2 = res * res % P, x4 = x2 * x2 % P, want5 = x4 * res % P;
+        if (fh64_canonical(fh64_sbox(xd)) != (uint32_t)want5) ok = false;
+        // and a whole partial round from a state whose s_0 sits at that magnitude: every output against integer arithmetic
+        double st[kFhT];
+        uint64_t ref[kFhT];
+#pragma unroll
+        for (int i = 0; i < kFhT; ++i) { st[i] = i ? (double)(l.w[i & 7] >> 1) - (double)(r.w[i & 7] >> 2) : xd; }
+#pragma unroll
+        for (int i = 0; i < kFhT; ++i) { const long long v = (long long)st[i]; ref[i] = (uint64_t)(((v % (long long)P) + (long long)P) % (long long)P); }
+        const double rc = g_fh_consts64.rc_part[t % kFhRP];
+        fh64_partial_round<true>(st, rc);
+        {
+            const uint64_t y = (ref[0] + (uint64_t)rc) % P, y2 = y * y % P, y4 = y2 * y2 % P;
+            ref[0] = y4 * y % P;
+            uint64_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < kFhT; ++i) sum = (sum + ref[i]) % P;
+            uint64_t outw[kFhT];
+            outw[0] = (sum + 2 * (P - ref[0])) % P;                   // d_0 = -2
+#pragma unroll
+            for (int i = 1; i < kFhT; ++i) outw[i] = (((uint64_t)1 << (i - 1)) % P * ref[i] + sum) % P;
+#pragma unroll
+            for (int i = 0; i < kFhT; ++i)
+                if (fh64_canonical(st[i]) != (uint32_t)outw[i]) ok = false;
+        }
     }
     if (!ok) { atomicAdd(bad, 1u); atomicMin(first_bad, t); }
 }

@@ -16,6 +16,7 @@
 // time) or the caller's own (tests: several ranks on one GPU).
 #include "shard.hpp"
 #include "board.hpp"
+#include "peer.hpp"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -116,6 +117,7 @@ struct zk_shard {
     const RcclApi* rccl = nullptr;                     // non-null: tp is the built-in RCCL transport
     ncclComm_t comm = nullptr;                         // collectives on `stream`
     ncclComm_t xcomm = nullptr;                        // chunked exchanges on `xstream`: their own communicator (null: comm serves both)
+    PeerTransport* peer = nullptr;                     // non-null: tp is the built-in peer-copy transport (zk_shard_options.peer_copy; peer.hpp)
     bool force = false;                                // collectives even with G = 1
     bool plain = false, single_build_stream = false, single_comm = false;   // zk_shard_options
     // every collective waits for the previous collective of the OTHER stream (explicit HIP event, whatever the transport)
@@ -217,6 +219,7 @@ int rank_failed(zk_shard* s, int rc) {
     if (!rc || s->failed) return rc;
     s->failed = true;
     if (s->have_board) s->board.post_abort((uint32_t)(-rc));
+    if (s->peer) s->peer->post_abort((uint32_t)(-rc));
     if (collectives(s)) fprintf(stderr, "[zk_shard] rank %d of %d failed (%d): %s\n", s->rank, s->G, rc, last_error());
     return rc;
 }
@@ -267,6 +270,18 @@ int rccl_all_gather(void* user, const uint32_t* send, uint32_t* recv, size_t wor
     zk_shard* s = static_cast<zk_shard*>(user);
     const ncclComm_t comm = ((hipStream_t)stream == s->xstream && s->xcomm) ? s->xcomm : s->comm;
     NCCLCHK(s, s->rccl->AllGather(send, recv, words, ncclUint32, comm, (hipStream_t)stream));
+    return ZK_OK;
+}
+
+// ---- built-in transport: peer copies through IPC handles (peer.hpp), no RCCL ------------------------------------
+int peer_all_to_all(void* user, const uint32_t* const* send, uint32_t* const* recv, size_t words, void* stream) {
+    zk_shard* s = static_cast<zk_shard*>(user);
+    if (s->peer->exchange(send, nullptr, recv, nullptr, words, (hipStream_t)stream)) return fail(ZK_ERR_HIP, "%s", s->peer->error.c_str());
+    return ZK_OK;
+}
+int peer_all_gather(void* user, const uint32_t* send, uint32_t* recv, size_t words, void* stream) {
+    zk_shard* s = static_cast<zk_shard*>(user);
+    if (s->peer->exchange(nullptr, send, nullptr, recv, words, (hipStream_t)stream)) return fail(ZK_ERR_HIP, "%s", s->peer->error.c_str());
     return ZK_OK;
 }
 
@@ -645,15 +660,26 @@ int decommit(zk_shard* s, Channel& ch, size_t x) {
             for (size_t i = 0; i < nv; ++i) cnt_v[pl.vit[i].owner] += 1;
             for (size_t i = 0; i < nd; ++i) cnt_d[pl.dit[i].owner] += 1;
             s->board.blob_post(++s->blob_seq, mine, 8 * mdg + mv);
+            // one clock for the whole exchange, and the peers' contributions COPIED out of the shared page: in place they are only
+            // valid until their owner posts the exchange after next (nothing enforced "consume before the next post")
+            const auto t_wait0 = std::chrono::steady_clock::now();
+            size_t total_words = 0;
+            for (int q = 0; q < G; ++q) total_words += 8 * cnt_d[q] + cnt_v[q];
+            s->blob_buf.resize(total_words);
+            size_t at = 0;
             for (int q = 0; q < G; ++q) {
                 if (q == me) { from[q] = mine; continue; }
-                const RootBoard::Status bs = s->board.blob_wait(s->blob_seq, q, &from[q], s->timeout_s);
+                const RootBoard::Status bs = s->board.blob_wait(s->blob_seq, q, &from[q], s->timeout_s, t_wait0);
                 if (bs == RootBoard::kPeerAborted)
                     return fail(ZK_ERR_HIP, "rank %d of %d: rank %d left the proof with error %d (seen in the decommitment exchange #%llu)", me, G,
                                 s->board.bad_peer, -(int)s->board.bad_code, (unsigned long long)s->blob_seq);
                 if (bs != RootBoard::kOk)
                     return fail(ZK_ERR_HIP, "rank %d of %d: rank %d did not post its openings (decommitment exchange #%llu timed out after %.0f s)", me, G,
                                 s->board.bad_peer, (unsigned long long)s->blob_seq, s->timeout_s);
+                const size_t words = 8 * cnt_d[q] + cnt_v[q];
+                memcpy(s->blob_buf.data() + at, from[q], words * sizeof(uint32_t));
+                from[q] = s->blob_buf.data() + at;
+                at += words;
             }
         } else {
             from[0] = mine; cnt_v[0] = nv; cnt_d[0] = nd;
@@ -901,7 +927,7 @@ int zk_shard_plan(int world, uint32_t log_n, uint32_t log_b, const zk_shard_opti
         if (opt->min_chunk_log) min_chunk_log = opt->min_chunk_log;
         if (opt->overlap_min_log) overlap_min_log = opt->overlap_min_log;
         force = opt->force_collectives != 0;
-        if (opt->plain_collectives) overlap_min_log = 99;          // plain collectives only: nothing is exchanged in chunks
+        if (opt->plain_collectives || opt->peer_copy) overlap_min_log = 99;   // plain collectives only: nothing is exchanged in chunks
     }
     const uint32_t L = log_n + log_b, R = log_n;
     if (L < 2 * lg + min_chunk_log)
@@ -957,6 +983,7 @@ int zk_shard_destroy(zk_shard* s) {
             fprintf(stderr, "[zk_shard] rank %d of %d: a collective of the caller's transport is still pending after a failure; "
                             "the prover's streams and device buffers are leaked instead of waited for\n", s->rank, s->G);
             s->board.close();
+            if (s->peer) { if (s->peer->page) munmap(s->peer->page, sizeof(PeerTransport::Page)); delete s->peer; }   // mapped peer memory is leaked with the rest
             delete s;
             return ZK_OK;
         }
@@ -967,6 +994,7 @@ int zk_shard_destroy(zk_shard* s) {
     if (s->xcomm && s->rccl) (void)s->rccl->CommDestroy(s->xcomm);
     if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
     s->board.close();
+    if (s->peer) { s->peer->close(); delete s->peer; s->peer = nullptr; }
     if (s->tail) zk_ctx_destroy(s->tail);
     if (s->committer) zk_committer_destroy(s->committer);
     if (s->dom_loc) zk_dom_destroy(s->dom_loc);
@@ -1008,7 +1036,7 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     if ((1 << lg) != world || lg > log_b || rank < 0 || rank >= world)
         return fail(ZK_ERR_INVALID, "zk_shard_create: world size %d must be a power of two dividing the blow-up %u, 0 <= rank < world", world, 1u << log_b);
     if (transport && (!transport->all_to_all || !transport->all_gather)) return fail(ZK_ERR_INVALID, "zk_shard_create: incomplete transport");
-    if (!transport && !id) return fail(ZK_ERR_INVALID, "zk_shard_create: the RCCL transport needs the shared unique id (zk_shard_unique_id)");
+    if (!transport && !id) return fail(ZK_ERR_INVALID, "zk_shard_create: the built-in transports need the shared 128 bytes (zk_shard_unique_id, or any bytes for peer_copy)");
     HIPCHK(hipSetDevice(device));
     zk_shard* s = new (std::nothrow) zk_shard();
     if (!s) return fail(ZK_ERR_NOMEM, "out of host memory");
@@ -1020,7 +1048,7 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         if (opt->min_chunk_log) s->min_chunk_log = opt->min_chunk_log;
         if (opt->overlap_min_log) s->overlap_min_log = opt->overlap_min_log;
         s->force = opt->force_collectives != 0;
-        s->plain = opt->plain_collectives != 0;
+        s->plain = opt->plain_collectives != 0 || opt->peer_copy != 0;
         s->single_build_stream = opt->single_build_stream != 0;
         s->single_comm = opt->single_communicator != 0;
     }
@@ -1065,6 +1093,21 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
     // transport
     if (transport) {
         s->tp = *transport;
+    } else if (opt && opt->peer_copy) {
+        // plain peer copies between the GPUs of this node (peer.hpp): the rung below RCCL.  Host-synchronous, so nothing is
+        // exchanged in chunks beside the hashing (zk_shard_plan: peer_copy implies plain collectives).
+        uint8_t dg[32];
+        Sha256 hsh; hsh.update(id, ZK_SHARD_ID_BYTES); hsh.update(reinterpret_cast<const uint8_t*>("peer"), 4); hsh.finalize(dg);
+        char pname[64];
+        snprintf(pname, sizeof pname, "/zkstark_amd_p%02x%02x%02x%02x%02x%02x%02x%02x", dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], dg[6], dg[7]);
+        s->peer = new (std::nothrow) PeerTransport();
+        if (!s->peer) return bail(fail(ZK_ERR_NOMEM, "out of host memory"));
+        if (!s->peer->open(pname, rank, world, s->timeout_s))
+            return bail(fail(ZK_ERR_HIP, "zk_shard_create: peer-copy transport (rank %d of %d): %s", rank, world, s->peer->error.c_str()));
+        s->tp.user = s;
+        s->tp.all_to_all = peer_all_to_all;
+        s->tp.all_gather = peer_all_gather;
+        s->stats.peer_copy = 1;
     } else {
         s->rccl = rccl_api();
         if (!s->rccl) return bail(ZK_ERR_STATE);

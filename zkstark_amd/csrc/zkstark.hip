@@ -75,6 +75,10 @@ struct zk_ctx {
     uint32_t* h_mailbox = nullptr;      // pinned, host-coherent, device-mapped: layout in kernels.hpp (MailArgs)
     uint32_t* d_mailbox = nullptr;      // the device view of h_mailbox
     uint32_t* d_counter = nullptr;      // one zeroed word: workgroups of a commit launch that are done
+    // A commit launch that was waited for in vain (wait_flag: device error, time-out) may have left the last-arriver counters of
+    // merkle_wg_kernel non-zero: only the workgroup that arrives last resets them.  Every later tree of this context would then
+    // pick the wrong "last" workgroup and post wrong digests silently, so the next launch zeroes them first.
+    bool counters_dirty = false;
     uint32_t mail_seq = 0;
     // Host-finished pieces of the one-call prover (host_sha.hpp): the top `host_top` levels of every tree
     // with more than 2^host_top leaves, and whole FRI layers of <= 2^host_tail values (fold + tree).
@@ -167,6 +171,10 @@ uint32_t top_of(const zk_ctx* c, uint32_t tree) {
 // folds on from there.
 MailArgs mail_of(zk_ctx* c, uint32_t tree, bool host, bool feed_tail = true) {
     MailArgs m;
+    if (c->counters_dirty) {                              // stream-ordered behind whatever is left of the failed launch
+        (void)hipMemsetAsync(c->d_counter, 0, 64, c->stream);
+        c->counters_dirty = false;
+    }
     m.mailbox = c->d_mailbox;
     m.seq = ++c->mail_seq;
     m.counter = c->d_counter;
@@ -209,6 +217,7 @@ int wait_mail(zk_ctx* c) {
     double t0 = now_us();
     int rc = wait_flag(c->h_mailbox, c->mail_seq, c->stream);
     c->t_wait += now_us() - t0;
+    if (rc) c->counters_dirty = true;
     return rc;
 }
 
@@ -756,10 +765,17 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     return ZK_OK;
 }
 
+#ifdef ZK_WG_TRACE
+extern "C++" { namespace zk { void dump_wg_trace(); } }   // kernels.hip: diagnostic build only (tools/wg_trace.py)
+#endif
+
 int zk_ctx_destroy(zk_ctx* c) {
     if (!c) return ZK_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef ZK_WG_TRACE
+    zk::dump_wg_trace();
+#endif
     dom_free(c->dom);
     if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_coef) (void)hipFree(c->d_coef);
@@ -1279,6 +1295,7 @@ struct zk_committer {
     uint32_t* h_mail = nullptr;     // pinned, mapped: MailArgs layout
     uint32_t* d_mail = nullptr;
     uint32_t* d_counter = nullptr;
+    bool counters_dirty = false;    // a commit launch was waited for in vain: zero the counters before the next one (as zk_ctx)
     uint32_t* h_stage = nullptr;    // pinned, mapped: host-built top nodes of up to kSlots commits, then kSlots ScatterSegs
     uint32_t* d_stage = nullptr;
     uint32_t seq = 0, top = 0;
@@ -1287,7 +1304,10 @@ struct zk_committer {
     // (committer_flush) -- not one launch per commit in front of the caller's next kernel.  base: the array every d_nodes of
     // a lazy commit points into.
     static constexpr uint32_t kSlots = 40;
-    static constexpr size_t kSlotWords = (size_t)8 << kHostTopSingle;
+    // a slot holds a commit's whole host-side scratch: the 2^top posted digests BEHIND the 2^top - 1 nodes built above them
+    // (committer_collect: 8 (2 cnt - 1) words).  Round 5 sized it for the nodes alone, so a commit spilled into the next,
+    // still empty, slot and the 40th would have run over the segment table (never reached: <= 32 commits per flush)
+    static constexpr size_t kSlotWords = (size_t)16 << kHostTopSingle;
     bool lazy = false;
     uint32_t* base = nullptr;
     uint32_t n_pending = 0;
@@ -1327,6 +1347,7 @@ int zk_committer_create(int device, zk_committer** out) {
     if (!k) return fail(ZK_ERR_NOMEM, "out of host memory");
     k->device = device;
     static_assert(zk_committer::kSlots * zk_committer::kSlotWords >= ((size_t)16 << kMaxHostLog), "staging: one eager commit fits");
+    static_assert(zk_committer::kSlotWords >= 8 * ((size_t)2 << kHostTopSingle) - 8, "staging: a lazy commit's nodes AND posted digests fit its own slot");
     const size_t stage_bytes = zk_committer::kSlots * zk_committer::kSlotWords * 4 + zk_committer::kSlots * sizeof(ScatterSeg);
     hipError_t e = hipHostMalloc((void**)&k->h_mail, kMailValsOff * 4, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&k->d_mail, k->h_mail, 0);
@@ -1348,6 +1369,11 @@ int zk_committer_set_top(zk_committer* k, uint32_t top_log) {
     k->top = top_log;
     return ZK_OK;
 }
+// The last-arriver counters of the next commit launch; zeroed first when an earlier launch was waited for in vain.
+static uint32_t* committer_counter(zk_committer* k, hipStream_t s) {
+    if (k->counters_dirty) { (void)hipMemsetAsync(k->d_counter, 0, 64, s); k->counters_dirty = false; }
+    return k->d_counter;
+}
 // Waits for the digests a commit launch posted; with a hand-over depth, hashes the levels above on this thread
 // and queues the copy of those nodes into d_nodes.
 static ScatterSeg* committer_segs(zk_committer* k, bool device) {
@@ -1365,7 +1391,7 @@ static int committer_flush_impl(zk_committer* k, hipStream_t s) {
 }
 static int committer_collect(zk_committer* k, const MailArgs& m, uint32_t* d_nodes, hipStream_t s, uint8_t root_out[32]) {
     int rc = wait_flag(k->h_mail, m.seq, s, k->poll, k->poll_user, k->timeout_s);
-    if (rc) return rc;
+    if (rc) { k->counters_dirty = true; return rc; }
     if (!m.top) { digest_words_to_bytes(k->h_mail + kMailDigests, root_out); return ZK_OK; }
     const size_t cnt = (size_t)1 << m.top;
     const bool lazy = k->lazy && k->base && d_nodes >= k->base;
@@ -1421,7 +1447,7 @@ int zk_dev_merkle_commit(zk_committer* k, const uint32_t* d_src, uint32_t log_pa
     MailArgs m;
     m.mailbox = k->d_mail;
     m.seq = ++k->seq;
-    m.counter = k->d_counter;
+    m.counter = committer_counter(k, s);
     m.top = (hash_kind == 0 && k->top && log_m > k->top) ? k->top : 0;
     if (log_parts) HIPCHK(launch_merkle_build_interleaved(d_src, log_parts, log_cnt, d_nodes, s, dev_prof(), hash_kind, m));
     else HIPCHK(launch_merkle_build(d_src, log_m, d_nodes, s, dev_prof(), m, hash_kind));
@@ -1452,7 +1478,7 @@ int dev_compose_block_commit(zk_committer* k, const zk_dom* glob, ComposeBlockAr
     MailArgs m;
     m.mailbox = k->d_mail;
     m.seq = ++k->seq;
-    m.counter = k->d_counter;
+    m.counter = committer_counter(k, s);
     m.top = (hash_kind == 0 && k->top && geom.log_m > k->top) ? k->top : 0;
     HIPCHK(launch_compose_block_merkle(geom, d_nodes, s, dev_prof(), m, hash_kind));
     if (enqueued)                                   // the caller's next launches go behind the hashing before this thread waits for the digests
@@ -1474,7 +1500,7 @@ int zk_dev_merkle_commit_finish(zk_committer* k, uint32_t* d_nodes, uint32_t log
     MailArgs m;
     m.mailbox = k->d_mail;
     m.seq = ++k->seq;
-    m.counter = k->d_counter;
+    m.counter = committer_counter(k, s);
     // the finish pass starts at the hand-over depth of the chunk builds; the host takes over only below that
     m.top = (hash_kind == 0 && k->top && merkle_finish_start_depth(log_m, log_chunks) > k->top) ? k->top : 0;
     HIPCHK(launch_merkle_finish(d_nodes, log_m, log_chunks, s, dev_prof(), hash_kind, m));

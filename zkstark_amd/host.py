@@ -426,9 +426,10 @@ class BatchContext:
 
 
 def shard_plan(world, log_n, log_blowup, min_layer_log=0, min_chunk_log=0, overlap_min_log=0, force_collectives=False, plain_collectives=False,
-               exchange_cp=False):
+               exchange_cp=False, peer_copy=False):
     """zk_shard_plan: the layout zk_shard_create would choose (no GPU needed); a dict of the zk_shard_plan_info fields."""
-    opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), 0, int(plain_collectives), 0, 0, int(exchange_cp), 0.0)
+    opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), 0, int(plain_collectives), 0, 0, int(exchange_cp), 0.0,
+                            int(peer_copy))
     pl = _lib.ShardPlan()
     check(_lib.load().zk_shard_plan(world, log_n, log_blowup, C.byref(opt), C.byref(pl)))
     d = {k: v for k, v in pl.fields().items() if k != "piece_log"}
@@ -450,12 +451,13 @@ class ShardContext:
 
     def __init__(self, log_n, log_blowup, rank, world, unique_id=None, device=0, transport=None, min_layer_log=0, min_chunk_log=0,
                  overlap_min_log=0, force_collectives=False, no_root_board=False, hash="sha256", queries=1, plain_collectives=False,
-                 single_build_stream=False, single_communicator=False, timeout_s=0.0, exchange_cp=False):
+                 single_build_stream=False, single_communicator=False, timeout_s=0.0, exchange_cp=False, peer_copy=False):
         self.log_n, self.log_blowup, self.rank, self.world = log_n, log_blowup, rank, world
         self.hash, self.queries = hash, queries
         self._transport = transport                      # keeps the callbacks alive
         opt = _lib.ShardOptions(min_layer_log, min_chunk_log, overlap_min_log, int(force_collectives), int(no_root_board),
-                                int(plain_collectives), int(single_build_stream), int(single_communicator), int(exchange_cp), float(timeout_s))
+                                int(plain_collectives), int(single_build_stream), int(single_communicator), int(exchange_cp), float(timeout_s),
+                                int(peer_copy))
         self._h = C.c_void_p()
         idb = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         check(_lib.load().zk_shard_create(device, rank, world, idb, C.byref(transport) if transport is not None else None,
