@@ -326,6 +326,12 @@ def test_tuning_surface_is_calls_not_environment(zk):
     for fn in os.listdir(csrc):
         with open(os.path.join(csrc, fn)) as f:
             names |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', f.read()))
+    # ZK_WG_TRACE_FILE exists in the DIAGNOSTIC build only (ZK_BUILD_DEFS="-DZK_WG_TRACE=1", tools/wg_trace.py): it must sit inside
+    # that #ifdef, so a product build still reads exactly two variables
+    kernels = open(os.path.join(csrc, "kernels.hip")).read()
+    at = kernels.index('getenv("ZK_WG_TRACE_FILE")')
+    assert kernels.rfind("#ifdef ZK_WG_TRACE", 0, at) > kernels.rfind("#endif", 0, at)
+    names.discard("ZK_WG_TRACE_FILE")
     assert names == {"ZK_HOST_TIMING", "ZK_SHARD_TIMEOUT_S"}, names
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert all(n in doc for n in names)
