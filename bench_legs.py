@@ -239,7 +239,13 @@ def fieldhash_2e24(R, log_n, log_b, trace, chain_field):
             "throughput_launches": {"count": int(leaf["launches"] + pk["merkle_inner"]["launches"]), "ms": leaf["ms"] + pk["merkle_inner"]["ms"]},
             "roofline": {"kernel": "merkle_subtree_kernel<leaf, field>", "bound": "valu", "unit": "T lane-ops/s (double precision)",
                          "achieved": (leaf["ops"] / (leaf["ms"] * 1e-3) / 1e12) if leaf["ms"] else None, "peak": mixp,
-                         "frac": (leaf["ops"] / (leaf["ms"] * 1e-3) / 1e12 / mixp) if leaf["ms"] else None, "traffic": traffic},
+                         "frac": (leaf["ops"] / (leaf["ms"] * 1e-3) / 1e12 / mixp) if leaf["ms"] else None,
+                         "launches": int(leaf["launches"]), "avg_launch_ms": leaf["ms"] / max(leaf["launches"], 1),
+                         "algorithmic_bytes_per_launch": leaf["bytes"] / max(leaf["launches"], 1),
+                         # HBM bytes per leaf launch from the PMC passes of the FIELD build (profiles/traffic_fieldhash.json, tools/pmc_traffic.py)
+                         "traffic": traffic["merkle_leaf_bytes_per_launch"] if traffic else None,
+                         "traffic_stamp": traffic["stamp"] if traffic else None,
+                         "traffic_from_this_build": bool(traffic and traffic["from_this_build"])},
             "chain": chain_field}
 
 

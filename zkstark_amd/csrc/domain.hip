@@ -27,12 +27,6 @@ const char* last_error() { return g_last_error.c_str(); }
 
 Plan make_plan(uint32_t log_m) {
     Plan p;
-    // (kernels.hpp: ZK_NTT_RADIX512, measured and off) 2^17 words in two passes of radix 512 x 256 instead of three
-    if (ZK_NTT_RADIX512 && log_m == 17) {
-        p.nd = 2;
-        p.bits[0] = 9; p.bits[1] = 8;
-        return p;
-    }
     uint32_t np = (log_m + kMaxRadixLog - 1) / kMaxRadixLog;
     if (np == 0) np = 1;
     uint32_t base = log_m / np, extra = log_m % np;

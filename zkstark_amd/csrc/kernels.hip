@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
 // workgroup barriers only; a launch therefore lowers the tree by j levels.
 constexpr int kWgThreads = 256;
 #ifndef ZK_FIELD_ROW_MAX_NODES
-#define ZK_FIELD_ROW_MAX_NODES 32
+#define ZK_FIELD_ROW_MAX_NODES 16       // round 6, re-swept with the quad form present (profiles/r06_ab_field_forms.txt): 32 nodes are one quad pass (5.3 us), not two row passes (7.2)
 #endif
 constexpr uint32_t kFieldRowMaxNodes = ZK_FIELD_ROW_MAX_NODES;   // levels of <= this many nodes per workgroup use the 16-lane row form of the field hash
 static_assert(kFieldRowMaxNodes >= 16 && kFieldRowMaxNodes <= 64, "the row form takes at most four passes of 16 nodes");
@@ -726,11 +726,40 @@ static_assert(kFieldRowMaxNodes >= 16 && kFieldRowMaxNodes <= 64, "the row form 
 #endif
 constexpr uint32_t kFieldQuadMaxNodes = ZK_FIELD_QUAD_MAX_NODES;   // ... of <= this many (and more than the row form's) one hash per quad of lanes; 0: never
 static_assert(kFieldQuadMaxNodes <= 128, "the quad form takes at most two passes of 64 nodes");
+#ifndef ZK_FIELD_ROW_LEAF_MAX
+#define ZK_FIELD_ROW_LEAF_MAX 32        // 0: leaves always one lane per hash
+#endif
+constexpr uint32_t kFieldRowLeafMax = ZK_FIELD_ROW_LEAF_MAX;     // a workgroup with <= this many LEAVES of the field hash hashes them in the row form too (round 6)
+static_assert(kFieldRowLeafMax <= 64, "the row form takes at most four passes of 16 leaves");
 constexpr uint32_t kWgMaxLog = 10;   // 1024 digests = 32 KiB LDS per workgroup
 
 __device__ __forceinline__ void lds_store(uint4* p, const Digest& d) {
     p[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
     p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+}
+
+// ---- handing a workgroup's result to the workgroup that finishes last (round 6) ----------------------------------------------
+// The chip has eight compute dies with an L2 each.  Rounds 1-5 published a workgroup's node with an agent-scope RELEASE on the
+// arrival counter (buffer_wbl2: write back the die's L2, ~0.5 MB of fresh digests per die in a 2^17-node launch) and the last
+// workgroup took everything in with an ACQUIRE (buffer_inv).  tools/wg_trace.py put 5.4 - 8.3 us per latency launch between "a
+// workgroup has its node" and "the last one starts the post" at EVERY tree size: that hand-over, not the hashing.  Only ONE node
+// per workgroup has to cross: it is re-stored with eight write-through stores (relaxed atomic stores at agent scope: sc1), the
+// wave waits for them, the counter is bumped RELAXED, and the last workgroup reads the nodes with agent-scope loads (sc1: they
+// miss the die's L2).  Everything else a launch wrote becomes visible at the kernel boundary as always.
+// Build-time A/B: ZK_BUILD_DEFS="-DZK_WG_RELAXED_PUBLISH=0" restores the release / acquire form.
+#ifndef ZK_WG_RELAXED_PUBLISH
+#define ZK_WG_RELAXED_PUBLISH 1
+#endif
+constexpr bool kWgRelaxedPublish = ZK_WG_RELAXED_PUBLISH != 0;
+__device__ __forceinline__ void publish_node(uint32_t* nodes, size_t node, const uint4* lvl0, uint32_t tid) {
+    if (tid < 8) __hip_atomic_store(nodes + node * 8 + tid, reinterpret_cast<const uint32_t*>(lvl0)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // wave 0: the eight stores are out before its thread 0 counts
+}
+__device__ __forceinline__ Digest load_digest_agent(const uint32_t* nodes, size_t node) {
+    Digest d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d.w[i] = __hip_atomic_load(nodes + node * 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return d;
 }
 
 // ---- diagnostic build: where the time of a latency launch goes (ZK_BUILD_DEFS="-DZK_WG_TRACE=1"; tools/wg_trace.py) ----------
@@ -781,7 +810,26 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     // a thread takes up to 2^kWgMaxLog / kWgThreads = 4 inputs: every read is issued before the first one is used (one
     // load latency per launch instead of one per input; this phase is a chain of latencies)
     constexpr uint32_t kPer = (1u << kWgMaxLog) / kWgThreads;
-    if (LEAF) {
+    if (LEAF && HASH == 1 && cnt <= kFieldRowLeafMax) {
+        // Few leaves of the field hash (the small trees of a proof's tail, spread over several workgroups): a leaf is the same
+        // permutation as a node, on (v, 0, ..., 0, 1), so it takes the 16-lane row form as well -- 3.6 us per pass of 16 leaves where
+        // the one-lane hash costs ~10.7 us however few there are (profiles/r06_wg_trace_21_field.txt: "load/leaf" of every leaf-mode
+        // launch).  Every lane of a row asks the source for the row's leaf (one address: the loads coalesce; a fused producer computes
+        // and stores the same value sixteen times over, which costs lanes that would idle anyway).
+        const uint32_t g = tid & 15u, grp = tid >> 4;
+#pragma unroll 1
+        for (uint32_t b = 0; b * 16 < cnt; ++b) {
+            const uint32_t i = b * 16 + grp;
+            const uint32_t ii = i < cnt ? i : 0u;                  // idle rows recompute leaf 0 (DPP needs whole rows running)
+            const uint32_t v = src.finish(src.fetch(first + ii - off), first + ii - off);
+            const uint32_t word = g == 0 ? v : g == 15 ? 1u : 0u;
+            const uint32_t res = fieldhash_inner_row16_f64(word, g, g_fh_consts64);
+            if (i < cnt && g < 8) {
+                nodes[(in_base + first + i) * 8 + g] = res;
+                reinterpret_cast<uint32_t*>(&lvl[2 * i])[g] = res;
+            }
+        }
+    } else if (LEAF) {
         typename SRC::Raw raw[kPer] = {};
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u)
@@ -969,16 +1017,22 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     // one alone reads the gridDim.x nodes back (the acquire has invalidated its CU's vector L1) and carries on.
     __shared__ uint32_t go_on;
     if (gridDim.x > 1) {
-        // every wave's digest stores have reached L2 before thread 0 releases them to the other compute dies: a wait on this
-        // wave's own stores, then the barrier; the agent-scope release itself (an L2 write-back) is paid ONCE per workgroup,
-        // by the atomic below (256 workgroups x 4 waves of agent-scope fences cost the SHA-256 path 4 us per tree)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (kWgRelaxedPublish) {
+            // this workgroup's node (lvl[0..1] after the last level) goes out write-through; nothing else has to cross dies
+            publish_node(nodes, (((size_t)1 << (depth_in - j)) - 1) + blockIdx.x, lvl, tid);
+        } else {
+            // every wave's digest stores have reached L2 before thread 0 releases them to the other compute dies: a wait on this
+            // wave's own stores, then the barrier; the agent-scope release itself (an L2 write-back) is paid ONCE per workgroup,
+            // by the atomic below (256 workgroups x 4 waves of agent-scope fences cost the SHA-256 path 4 us per tree)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
     if (tid == 0) {
         uint32_t last = 1;
         if (gridDim.x > 1) {
-            last = __hip_atomic_fetch_add(mail.counter + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            last = (kWgRelaxedPublish ? __hip_atomic_fetch_add(mail.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : __hip_atomic_fetch_add(mail.counter + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)) == gridDim.x - 1;
             if (last) __hip_atomic_store(mail.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         go_on = last;
@@ -995,7 +1049,8 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
         Digest dd[kPer];
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u)
-            if (tid + u * kWgThreads < cnt) dd[u] = load_digest(nodes, base2 + tid + u * kWgThreads);
+            if (tid + u * kWgThreads < cnt)
+                dd[u] = (kWgRelaxedPublish && gridDim.x > 1) ? load_digest_agent(nodes, base2 + tid + u * kWgThreads) : load_digest(nodes, base2 + tid + u * kWgThreads);
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u)
             if (tid + u * kWgThreads < cnt) lds_store(&lvl[2 * (tid + u * kWgThreads)], dd[u]);
@@ -1007,11 +1062,16 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     // host: small PCIe writes are slow, so the workgroup that finishes last copies everything with wide stores.
     if (mail.mailbox && depth_in - j - j2 == mail.top && off == 0) {
         __shared__ uint32_t is_last;
+        // one node per workgroup crosses the dies write-through (publish_node); a launch that also posts layer values keeps the
+        // release / acquire form, which covers them as well (once per proof: the layer that feeds the host's FRI tail)
+        const bool relaxed = kWgRelaxedPublish && gridDim.x > 1 && j2 == 0 && mail.dump_src == nullptr;   // uniform over the launch
+        if (relaxed) publish_node(nodes, (((size_t)1 << mail.top) - 1) + blockIdx.x, lvl, tid);
         if (tid == 0) {
             uint32_t last = 1;
             if (gridDim.x > 1 && j2 == 0) {                        // with a continuation only the last workgroup gets here
                 // release: this workgroup's digest (and values) are out; acquire: so are everybody else's
-                last = __hip_atomic_fetch_add(mail.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+                last = (relaxed ? __hip_atomic_fetch_add(mail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : __hip_atomic_fetch_add(mail.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)) == gridDim.x - 1;
                 if (last) __hip_atomic_store(mail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             is_last = last;
@@ -1024,7 +1084,15 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
 #endif
             const uint4* sq = reinterpret_cast<const uint4*>(nodes + (((size_t)1 << mail.top) - 1) * 8);
             uint4* dq = reinterpret_cast<uint4*>(mail.mailbox + kMailDigests);
-            for (uint32_t i = tid; i < (2u << mail.top); i += kWgThreads) dq[i] = sq[i];
+            if (relaxed) {                                         // the peers' nodes: agent-scope loads (they are not in this die's L2)
+                for (uint32_t i = tid; i < (1u << mail.top); i += kWgThreads) {
+                    const Digest d = load_digest_agent(nodes, (((size_t)1 << mail.top) - 1) + i);
+                    dq[2 * i] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+                    dq[2 * i + 1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+                }
+            } else {
+                for (uint32_t i = tid; i < (2u << mail.top); i += kWgThreads) dq[i] = sq[i];
+            }
             if (mail.dump_src) {
                 const uint4* sv = reinterpret_cast<const uint4*>(mail.dump_src);
                 uint4* dv = reinterpret_cast<uint4*>(mail.mailbox + mail.vals_off);
@@ -1130,12 +1198,14 @@ bool set_merkle_latency_log(uint32_t v) {
 // on a lone wave), a row of 16 lanes in double precision 3.9 (16 per pass; the 32-bit row form of rounds 3-4: 5.4).
 static double wg_level_us(uint32_t w, int hash) {
     if (w == 0) return 0.0;
-    if (hash) return w <= kFieldRowMaxNodes ? (double)((w + 15) / 16) * 3.9 : w <= kFieldQuadMaxNodes ? (double)((w + 63) / 64) * 6.0 : (double)((w + 255) / 256) * 11.0;
+    if (hash) return w <= kFieldRowMaxNodes ? (double)((w + 15) / 16) * 3.7 : w <= kFieldQuadMaxNodes ? (double)((w + 63) / 64) * 5.3 : (double)((w + 255) / 256) * 10.8;   // round 6: as traced (tools/wg_trace.py)
     return w <= 64 ? 3.1 : w <= 128 ? 4.9 : (double)((w + 255) / 256) * 4.6;
 }
 static double wg_phase_us(bool leaf, uint32_t cnt_log, uint32_t levels, int hash, uint32_t blocks) {
     const uint32_t cnt = 1u << cnt_log;
-    double us = leaf ? (double)((cnt + 255) / 256) * (hash ? 11.0 : 2.6) : 1.0;   // leaf hashes, or the first load
+    double us = !leaf ? 1.0                                                        // the first load, or the leaf hashes:
+                : hash ? (cnt <= kFieldRowLeafMax ? (double)((cnt + 15) / 16) * 3.7 : (double)((cnt + 255) / 256) * 10.8)
+                       : (double)((cnt + 255) / 256) * 2.6;
     for (uint32_t t = 1; t <= levels; ++t) us += wg_level_us(cnt >> t, hash);
     return blocks > 256 ? us * (double)blocks / 256.0 : us;                        // more workgroups than compute units take turns
 }

@@ -89,13 +89,8 @@ enum NttMode : uint32_t {
 #ifndef ZK_NTT_SMALL_MAX_LOG
 #define ZK_NTT_SMALL_MAX_LOG 20
 #endif
-// Radix-512 passes (16 x 32 register DFTs) so that a transform of 2^17 words takes two passes instead of three: built and measured
-// in round 5 (tools/ab_ntt_radix512.sh, profiles/r05_ab_ntt_radix512.txt): parity-green and SLOWER -- the two long passes (14.4 and
-// 9.7 us: half the threads idle in step 2, 32-point register DFTs, 32-byte row segments) cost more than the four 5-6 us passes they
-// replace; configs[1] 203 against 190 us.  Off; -DZK_NTT_RADIX512=1 builds it.
-#ifndef ZK_NTT_RADIX512
-#define ZK_NTT_RADIX512 0
-#endif
+// (Radix-512 passes -- 2^17 words in two passes instead of three -- were built and measured in round 5: parity-green and SLOWER,
+// configs[1] 203 against 190 us, profiles/r05_ab_ntt_radix512.txt.  The branch was removed in round 6; the record stays.)
 constexpr uint32_t kMidTileLog = 12, kSmallTileLog = 11;
 constexpr uint32_t kNttSmallTileMaxLog = ZK_NTT_SMALL_MAX_LOG;
 inline uint32_t ntt_tile_log(uint32_t log_total) { return log_total <= kNttSmallTileMaxLog ? kSmallTileLog : kMidTileLog; }

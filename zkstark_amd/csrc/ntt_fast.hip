@@ -1,4 +1,5 @@
-// ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256; 512 as a build option, measured slower).
+// ntt_fast.hip -- register-radix NTT pass (R = 32, 64, 128, 256; radix 512 was built and measured slower in round 5:
+// profiles/r05_ab_ntt_radix512.txt, removed in round 6).
 //
 // Same pass semantics as ntt_pass_kernel (kernels.hip): the array is [A][R][S], a workgroup owns
 // C columns x R rows.  The tile is R*C = 4096 words, 2048 for transforms of up to 2^20 words
@@ -381,11 +382,6 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
         case 6: return launch2<MODE, 3, 3>(a, staged, blocks, s);
         case 7: return launch2<MODE, 4, 3>(a, staged, blocks, s);
         case 8: return launch2<MODE, 4, 4>(a, staged, blocks, s);
-#if ZK_NTT_RADIX512
-        // radix 512 = 16 x 32 (round 5, measured slower and off: kernels.hpp).  4096-word tile only (8 columns: 32-byte row segments);
-        // every thread has one 16-point item in step 1, half of them a 32-point item in step 2
-        case 9: return launch3<MODE, 4, 5, (int)kMidTileLog>(a, staged, blocks, s);
-#endif
     }
     return hipErrorInvalidValue;
 }
@@ -395,9 +391,8 @@ hipError_t launch1(const NttPassArgs& a, bool staged, uint32_t blocks, hipStream
 // True when launch_ntt_pass_fast will take this pass (the planner asks before it fuses the coefficient
 // preparation into the first LDE pass, which only this kernel implements).
 bool ntt_fast_ok(const NttPassArgs& a, NttMode mode) {
-    if (a.logR < 5 || a.logR > (ZK_NTT_RADIX512 ? 9u : 8u)) return false;
+    if (a.logR < 5 || a.logR > 8) return false;
     if (a.tile_log != kSmallTileLog && a.tile_log != kMidTileLog) return false;
-    if (a.logR == 9 && a.tile_log != kMidTileLog) return false;
     const uint32_t logC = a.tile_log - a.logR;
     if (a.log_total < a.tile_log || a.logC != logC) return false;
     if (mode == NTT_DIT_LDE && !(a.logS < logC)) return false;
