@@ -51,6 +51,17 @@ __global__ void __launch_bounds__(256) param_kernel(const uint32_t* src, uint32_
     }
 }
 
+// the same with an ORDINARY (cacheable) load: how kernel arguments themselves are read.  Freshness is checked on the host (out[] must
+// hold the value written just before this launch was released).
+__global__ void __launch_bounds__(256) param_plain_kernel(const uint32_t* __restrict__ src, uint32_t* out, volatile uint32_t* done, uint32_t seq, uint32_t* counter) {
+    const uint32_t v = src[0];
+    out[blockIdx.x * 256 + threadIdx.x] = v + threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(counter, 1u) == gridDim.x - 1) { *counter = 0; *done = seq; __threadfence_system(); }
+    }
+}
+
 static void stats(const char* name, std::vector<double>& v) {
     std::sort(v.begin(), v.end());
     printf("%-58s median %6.2f us   p10 %6.2f   p90 %6.2f   min %6.2f\n", name, v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10], v[0]);
@@ -86,6 +97,37 @@ int main() {
         if (i >= 20) v.push_back(now_us() - t0);
     }
     stats("A  plain launch when the value is known", v);
+    // A': the same onto a HOT queue: the previous kernel ended 8 us ago (what a commitment's host turn looks like), not 150 us ago
+    for (double gap : {8.0, 20.0}) {
+        v.clear();
+        for (int i = 0; i < reps + 20; ++i) {
+            ++seq;
+            { const double t = now_us(); while (now_us() - t < gap) {} }
+            const double t0 = now_us();
+            hipLaunchKernelGGL(done_kernel, dim3(1), dim3(64), 0, st, d_done, seq);
+            if (!wait_done(h_done, seq)) { fprintf(stderr, "A' timed out\n"); return 1; }
+            if (i >= 20) v.push_back(now_us() - t0);
+        }
+        char nm[96];
+        snprintf(nm, sizeof nm, "A' plain launch, previous kernel ended %.0f us ago", gap);
+        stats(nm, v);
+    }
+    // B'': wait-value + kernel enqueued early, released 8 us after the previous kernel ended (the hot-queue counterpart of A')
+    {
+        v.clear();
+        bool ok = true;
+        for (int i = 0; i < reps + 20 && ok; ++i) {
+            ++seq;
+            if (hipStreamWaitValue32(st, d_gate, seq, hipStreamWaitValueEq, 0xFFFFFFFFu) != hipSuccess) { ok = false; break; }
+            hipLaunchKernelGGL(done_kernel, dim3(1), dim3(64), 0, st, d_done, seq);
+            { const double t = now_us(); while (now_us() - t < 8.0) {} }
+            const double t0 = now_us();
+            *reinterpret_cast<volatile uint32_t*>(h_gate) = seq;
+            if (!wait_done(h_done, seq)) { fprintf(stderr, "B'' timed out\n"); return 1; }
+            if (i >= 20) v.push_back(now_us() - t0);
+        }
+        if (ok) stats("B\" wait-value + kernel enqueued early, released 8 us after the previous kernel", v);
+    }
 
     // B: hipStreamWaitValue32 on a host-written word, enqueued early
     int can = 0;
@@ -164,6 +206,37 @@ int main() {
             if (i >= 20) v.push_back(now_us() - t0);
         }
         stats(names[kind], v);
+    }
+    // Q: ordinary loads of a parameter block in host memory (coherent / non-coherent), plain launch and pre-enqueued behind a wait-value;
+    //    the value changes every repetition and the first output word is checked against it (a stale cache line would show)
+    uint32_t* h_out;
+    CHECK(hipHostMalloc((void**)&h_out, 64));
+    for (int kind = 0; kind < 4 && can; ++kind) {
+        const bool noncoh = kind & 1, early = kind & 2;
+        uint32_t* hp = noncoh ? h_nc : h_gate + 8;             // the parameter word (coherent: another word of the gate's line + 32 B)
+        const uint32_t* dp = noncoh ? d_nc : d_gate + 8;
+        v.clear();
+        int stale = 0;
+        for (int i = 0; i < reps + 20; ++i) {
+            ++seq;
+            if (early) {
+                if (hipStreamWaitValue32(st, d_gate, seq, hipStreamWaitValueEq, 0xFFFFFFFFu) != hipSuccess) { printf("Q wait-value failed\n"); break; }
+                hipLaunchKernelGGL(param_plain_kernel, dim3(1024), dim3(256), 0, st, dp, d_out, d_done, seq, d_counter);
+            }
+            settle();
+            const double t0 = now_us();
+            *reinterpret_cast<volatile uint32_t*>(hp) = seq * 7u + 1u;                    // the "challenge"
+            __sync_synchronize();
+            if (early) *reinterpret_cast<volatile uint32_t*>(h_gate) = seq;
+            else hipLaunchKernelGGL(param_plain_kernel, dim3(1024), dim3(256), 0, st, dp, d_out, d_done, seq, d_counter);
+            if (!wait_done(h_done, seq)) { fprintf(stderr, "Q timed out\n"); return 1; }
+            if (i >= 20) v.push_back(now_us() - t0);
+            CHECK(hipMemcpy(h_out, d_out, 8, hipMemcpyDeviceToHost));
+            if (h_out[0] != seq * 7u + 1u) ++stale;
+        }
+        char name[160];
+        snprintf(name, sizeof name, "Q  1024 wgs, ORDINARY load from %s host memory, %s [stale %d]", noncoh ? "NON-COHERENT" : "COHERENT", early ? "wait-value, early" : "plain launch", stale);
+        stats(name, v);
     }
     CHECK(hipStreamSynchronize(st));
     printf("done\n");
