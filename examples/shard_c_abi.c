@@ -4,7 +4,8 @@
  * (include/zkstark_amd.h: zk_shard_*).  Rank 0 obtains the RCCL unique id, every thread creates its shard collectively,
  * uploads the same trace and proves; every rank must return the same bytes, equal to zk_prove's on one GPU.
  *   gcc -O2 -pthread -Iinclude examples/shard_c_abi.c -Lzkstark_amd -lzkstark_amd -Wl,-rpath,$PWD/zkstark_amd -o shard_c_abi
- *   ./shard_c_abi [world] [log_n] [log_blowup]        (world GPUs must be visible; world = 1 exercises RCCL with one rank)
+ *   ./shard_c_abi [world] [log_n] [log_blowup] [peer]  (world GPUs must be visible; world = 1 exercises RCCL with one rank;
+ *                                                        a 4th argument "peer" uses the library's peer-copy transport instead: no RCCL)
  */
 #include <pthread.h>
 #include <stdint.h>
@@ -13,6 +14,8 @@
 #include <string.h>
 
 #include "zkstark_amd.h"
+
+static int g_peer_copy;       /* argv[4] == "peer": zk_shard_options.peer_copy (IPC handles + device-to-device copies, csrc/peer.hpp) */
 
 typedef struct {
     int rank, world, rc;
@@ -31,9 +34,12 @@ static void *run_rank(void *p) {
     zk_shard_options opt;
     ZK_STRUCT_INIT(&opt);                               /* zeroes it and sets opt.struct_size = sizeof opt (checked by the library) */
     ZK_STRUCT_INIT(&a->stats);
-    opt.force_collectives = 1;                          /* with world = 1: still go through RCCL */
+    opt.force_collectives = 1;                          /* with world = 1: still go through the transport */
+    opt.peer_copy = g_peer_copy;
     if (a->log_n + a->log_b < 22) { opt.min_layer_log = 1; opt.min_chunk_log = 6; }   /* small demo sizes: shard anyway */
-    a->rc = zk_shard_create(a->rank /* GPU */, a->rank, a->world, a->id, NULL /* RCCL */, &opt, a->log_n, a->log_b, &sp);
+    /* one GPU per rank; ZK_EXAMPLE_SHARE_GPU=1 puts every rank on GPU 0 (a one-GPU box: only the peer-copy transport can do that) */
+    const int gpu = getenv("ZK_EXAMPLE_SHARE_GPU") ? 0 : a->rank;
+    a->rc = zk_shard_create(gpu, a->rank, a->world, a->id, NULL /* built-in transport: RCCL, or peer copies */, &opt, a->log_n, a->log_b, &sp);
     if (!a->rc) a->rc = zk_shard_trace_upload(sp, a->trace, ((size_t)1 << a->log_n) - 1);
     if (!a->rc) a->rc = zk_shard_prove(sp, a->proof, a->cap, &a->len, a->state);   /* collective */
     if (!a->rc) a->rc = zk_shard_get_stats(sp, &a->stats);
@@ -54,7 +60,9 @@ int main(int argc, char **argv) {
     uint32_t *trace = malloc((n - 1) * sizeof *trace);
     if (zk_trace_fibsq(1, 3141592, n - 1, trace)) return 1;          /* prover.rs:32-39 */
     uint8_t id[ZK_SHARD_ID_BYTES];
-    if (zk_shard_unique_id(id)) { fprintf(stderr, "zk_shard_unique_id: %s\n", zk_last_error()); return 1; }
+    g_peer_copy = argc > 4 && !strcmp(argv[4], "peer");
+    if (g_peer_copy) { for (int i = 0; i < ZK_SHARD_ID_BYTES; ++i) id[i] = (uint8_t)(rand() ^ (i * 41)); }   /* any shared bytes: they name the page */
+    else if (zk_shard_unique_id(id)) { fprintf(stderr, "zk_shard_unique_id: %s\n", zk_last_error()); return 1; }
     rank_args args[8];
     pthread_t th[8];
     for (int r = 0; r < world; ++r) {
@@ -80,8 +88,8 @@ int main(int argc, char **argv) {
     if (len1 != args[0].len || memcmp(one, args[0].proof, len1) || memcmp(st1, args[0].state, 32)) { fprintf(stderr, "sharded proof differs from zk_prove\n"); return 1; }
     if (zk_verify_strict(args[0].proof, args[0].len, args[0].state, log_n, log_b, trace[n - 2])) { fprintf(stderr, "%s\n", zk_last_error()); return 1; }
     printf("world %d: %zu proof bytes on every rank, equal to zk_prove; verifier accepts\n", world, args[0].len);
-    printf("sharded layers %u, native rccl %u, root board %u, sent to peers %.0f bytes per rank\n", args[0].stats.sharded_layers,
-           args[0].stats.native_rccl, args[0].stats.root_board, args[0].stats.sent_bytes);
+    printf("sharded layers %u, native rccl %u, peer copy %u, root board %u, sent to peers %.0f bytes per rank\n", args[0].stats.sharded_layers,
+           args[0].stats.native_rccl, args[0].stats.peer_copy, args[0].stats.root_board, args[0].stats.sent_bytes);
     printf("proof head:");
     for (int i = 0; i < 8; ++i) printf(" %02x", args[0].proof[i]);
     printf("\n");

@@ -377,6 +377,13 @@ def test_shard_from_plain_c(tmp_path, orc):
     assert f"world 1: {len(want.proof)} proof bytes on every rank, equal to zk_prove" in out.stdout
     assert "native rccl 1" in out.stdout
     assert "proof head: " + " ".join(f"{b:02x}" for b in want.proof[:8]) in out.stdout
+    # the same program on the library's peer-copy transport (no RCCL): one rank, then two and four ranks as THREADS sharing the GPU
+    # (ranks of one process hand each other raw pointers instead of IPC handles)
+    for world in ("1", "2", "4"):
+        out = subprocess.run([exe, world, "12", "3", "peer"], capture_output=True, text=True, timeout=240, env=dict(env, ZK_EXAMPLE_SHARE_GPU="1"))
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert f"world {world}: {len(want.proof)} proof bytes on every rank, equal to zk_prove" in out.stdout
+        assert "native rccl 0, peer copy 1" in out.stdout
 
 
 @pytest.fixture(scope="module")
