@@ -187,7 +187,17 @@ def _worker(rank, world, port, log_n, log_b, opts, q, mode, uid):
         tp = None if opts.get("peer_copy") else gloo_transport()
         with zk.ShardContext(log_n, log_b, rank, world, uid, transport=tp, timeout_s=30.0, **opts) as sp:
             sp.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
-            if mode == "prove":
+            if mode == "fail":                             # the last rank leaves the proof with an error: nobody may hang
+                import time
+                if rank == world - 1:
+                    sp.inject_failure()
+                t0 = time.time()
+                try:
+                    sp.prove()
+                    q.put((rank, "proved", "", time.time() - t0))
+                except zk.ZkError as e:
+                    q.put((rank, "error", str(e), time.time() - t0))
+            elif mode == "prove":
                 proof = sp.prove()
                 info = sp.last_transcript()
                 q.put((rank, proof.data, proof.state, [bytes(r) for r in info.roots[:log_n + 2]], sp.stats()))
@@ -302,6 +312,19 @@ def test_shard_peer_copy_transport_matches_oracle(orc, world, log_n, log_b, opts
         assert (st["sharded_layers"], st["all_to_all_bytes"]) == (pl["sharded_layers"], pl["all_to_all_bytes"])
 
 
+def test_shard_peer_copy_failure_of_one_rank_is_contained():
+    """Four processes on the peer-copy transport; the last one leaves the proof with an error (zk_shard_inject_failure).  The others
+    must come back with an error naming it within seconds -- the abort word on the transport's page ends their waits -- not after
+    timeout_s (30 s here) and not never."""
+    out = _run(4, 14, 3, dict(min_layer_log=1, min_chunk_log=6, peer_copy=True), "fail", timeout=200)
+    for rank, what, msg, dt in out:
+        assert what == "error", (rank, what, msg)
+        assert dt < 15.0, (rank, dt, msg)
+        if rank != 3:                                      # the rank that left, or a peer that had already left because of it
+            assert "left the proof with error" in msg, msg
+    assert any("rank 3 left" in msg for rank, what, msg, dt in out if rank != 3), out
+
+
 def test_shard_peer_copy_one_rank_and_a_peer_that_never_comes(zk, orc):
     """One rank with the collectives forced goes through the peer-copy code with itself as the only peer; a rank whose peer never
     arrives gets an error naming what it waited for within timeout_s (not a hang)."""
@@ -331,6 +354,12 @@ def test_shard_two_ranks_production_sizes_2e25(orc):
         assert data == want.proof and state == want.state, f"rank {rank}"
         assert roots == [bytes(r) for r in want.roots], f"rank {rank}"
         assert st["sharded_layers"] == 5 and st["chunked_layers"] == 3 and st["root_board"] == 1
+    # the same size on the library's peer-copy transport (round 6): shards whose tree array is 3.2 GB -- the size at which the first
+    # version of that transport, which exported the caller's own allocations, never came back from mapping one (docs/LOG.md)
+    out = _run(world, log_n, 3, dict(peer_copy=True), "prove", timeout=240)
+    for rank, data, state, roots, st in out:
+        assert data == want.proof and state == want.state, f"rank {rank} (peer copy)"
+        assert st["sharded_layers"] == 5 and st["chunked_layers"] == 0 and st["peer_copy"] == 1
 
 
 def test_shard_four_ranks_production_sizes_2e26(orc):

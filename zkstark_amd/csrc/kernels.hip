@@ -1039,6 +1039,9 @@ __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t
     }
     __syncthreads();
     if (!go_on) return;                                            // workgroup-uniform
+    // a launch that also posts layer values (once per proof): the values the OTHER workgroups stored (behind their __threadfence
+    // above) are read by this one with ordinary loads at the end -- take them in with an acquire, as the counter did in rounds 1-5
+    if (kWgRelaxedPublish && LEAF && mail.dump_src) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #ifdef ZK_WG_TRACE
     if (tid == 0) wg_rec = __hip_atomic_load(&g_wg_trace_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroup 0 wrote it before it reached the counter
     WG_STAMP(15);

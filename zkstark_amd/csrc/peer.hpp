@@ -1,18 +1,17 @@
 // peer.hpp -- the two collectives of zk_shard_transport as plain peer copies between the GPUs of ONE node: no RCCL.
 //
 // The fall-back rung of the sharded prover below "RCCL, plain collectives" (zk_shard_options.peer_copy; bench.py --gpus N
-// tries it when RCCL cannot be brought up): every rank publishes, per collective, where the piece for each peer lies -- an
-// IPC handle of the allocation (hipIpcGetMemHandle) plus a byte offset -- on a POSIX shared-memory page, the receiver maps
-// the allocation once (hipIpcOpenMemHandle, cached) and PULLS its piece with a device-to-device copy on the caller's
-// stream.  Host-synchronous by construction (a stream synchronisation and a meeting on the page before and after the
+// tries it when RCCL cannot be brought up): every rank owns ONE staging buffer whose IPC handle (hipIpcGetMemHandle) it
+// publishes on a POSIX shared-memory page at creation; the peers map it once (hipIpcOpenMemHandle).  Per collective a rank
+// copies its pieces into its staging buffer, announces the collective on the page, and every rank PULLS its piece from each
+// peer's staging buffer with a device-to-device copy on the caller's stream.  Host-synchronous by construction (a stream synchronisation and a meeting on the page before and after the
 // copies), so nothing overlaps the hashing: it is there to yield a correct, measured line when a communicator cannot be
 // formed, not to be fast.  Ranks that live in the same process (threads) hand each other raw pointers instead of handles.
 //
 // Protocol of collective k = 1, 2, ... (the same number on every rank):
-//   1. my send pieces are complete (hipStreamSynchronize); write my G entries; release-store posted = k;
-//   2. for every peer q: wait posted[q] >= k, read q's entry for me, enqueue the copy;
-//   3. hipStreamSynchronize; release-store done = k; wait done[q] >= k for every q (nobody reuses a send buffer earlier).
-// One message buffer per rank suffices: a rank writes the entries of k + 1 only after step 3 of k.
+//   1. my pieces are in my staging buffer (local copies, then hipStreamSynchronize); release-store posted = k;
+//   2. for every peer q: wait posted[q] >= k, enqueue the copy of my piece out of q's staging buffer;
+//   3. hipStreamSynchronize; release-store done = k; wait done[q] >= k for every q (nobody refills its staging buffer earlier).
 #pragma once
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
@@ -25,25 +24,30 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
 #include <string>
 #include <vector>
+
+// Diagnostic build (ZK_BUILD_DEFS="-DZK_PEER_DEBUG=1"): every step of every collective on stderr with a time stamp.
+#ifdef ZK_PEER_DEBUG
+#define PEER_DBG(...) do { fprintf(stderr, "[peer %d %.6f] ", rank, now_s()); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } while (0)
+#else
+#define PEER_DBG(...) do { } while (0)
+#endif
 
 namespace zk {
 namespace impl {
 
 struct PeerTransport {
     static constexpr int kMaxWorld = 32;
-    static constexpr uint64_t kMagic = 0x7a6b706565723031ull;      // "zkpeer01"
-    struct Entry {                                                 // where the piece for one destination lies
-        uint8_t handle[64];                                        // hipIpcMemHandle_t of the allocation
-        uint64_t offset;                                           // byte offset of the piece inside it
-        uint64_t raw;                                              // the sender's own pointer (same-process peers)
-        uint64_t pid;
-    };
+    static constexpr uint64_t kMagic = 0x7a6b706565723032ull;      // "zkpeer02"
     struct Slot {
-        uint64_t posted, done;
-        uint32_t abort_code, pad[11];
-        Entry to[kMaxWorld];
+        uint64_t posted, done;                                     // collective numbers (release / acquire)
+        uint64_t words;                                            // of the collective `posted` announces (consistency check)
+        uint32_t abort_code, ready;                                // ready: the staging buffer below is published
+        uint8_t handle[64];                                        // hipIpcMemHandle_t of this rank's staging buffer
+        uint64_t stage_bytes, raw, pid;                            // its size, its address in the owner's process (same-process peers), the owner
+        uint64_t pad[2];
     };
     struct Page {
         uint64_t magic;
@@ -56,16 +60,21 @@ struct PeerTransport {
     double timeout_s = 120.0;
     uint64_t seq = 0;
     std::string name, error;
-    struct Opened { uint8_t handle[64]; void* base; };
-    std::vector<Opened> opened[kMaxWorld];                         // peer allocations this rank has mapped
-    struct Mine { void* base; hipIpcMemHandle_t handle; };
-    std::vector<Mine> mine;                                        // this rank's allocations with their handles
+    // Every piece travels through ONE staging buffer per rank, allocated here and mapped by the peers once, at creation: the
+    // caller's own allocations are never exported.  (The first version published a handle of whatever allocation a send pointer
+    // lay in; mapping the 3.2 GB tree array of a 2^24-element shard for an 8-word all-gather never returned from
+    // hipIpcOpenMemHandle, in both processes at once -- docs/LOG.md, round 6 item 5.  The extra local copy is ~10 us per 32 MB.)
+    uint32_t* stage = nullptr;
+    size_t stage_bytes = 0;
+    const char* peer_stage[kMaxWorld] = {};                        // peers' staging buffers as mapped here (own: stage)
+    bool opened[kMaxWorld] = {};
     int bad_peer = -1;
 
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-    // Rank 0 creates the page, the others wait for it (bounded); the name goes once every rank has mapped it.
-    bool open(const char* shm_name, int rank_, int world, double timeout) {
+    // Rank 0 creates the page, the others wait for it (bounded); the name goes once every rank has mapped it.  Then every rank
+    // allocates and publishes its staging buffer (bytes: the largest collective, G pieces of the largest piece) and maps its peers'.
+    bool open(const char* shm_name, int rank_, int world, double timeout, size_t bytes) {
         rank = rank_; G = world; timeout_s = timeout; name = shm_name;
         if (world > kMaxWorld) { error = "world size above 32"; return false; }
         const double t0 = now_s();
@@ -105,13 +114,42 @@ struct PeerTransport {
             sched_yield();
         }
         if (rank == 0) shm_unlink(shm_name);                        // the name goes in every case: nothing is left in /dev/shm
-        return all;
+        if (!all) return false;
+        // the staging buffer: allocate, publish, map the peers'
+        stage_bytes = (bytes + 255) & ~(size_t)255;
+        if (hipMalloc((void**)&stage, stage_bytes) != hipSuccess) { error = "hipMalloc of the staging buffer failed"; stage = nullptr; return false; }
+        Slot& my = page->slot[rank];
+        hipIpcMemHandle_t h;
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+        if (hipIpcGetMemHandle(&h, stage) != hipSuccess) { error = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(hipGetLastError()); return false; }
+        memcpy(my.handle, &h, 64);
+        my.stage_bytes = stage_bytes; my.raw = (uint64_t)(uintptr_t)stage; my.pid = (uint64_t)getpid();
+        __atomic_store_n(&my.ready, 1u, __ATOMIC_RELEASE);
+        for (int q = 0; q < G; ++q) {
+            Slot& sl = page->slot[q];
+            while (!__atomic_load_n(&sl.ready, __ATOMIC_ACQUIRE)) {
+                if (now_s() - t0 > timeout_s) { error = "rank " + std::to_string(q) + " never published its staging buffer (peer-copy transport)"; return false; }
+                sched_yield();
+            }
+            if (q == rank || sl.pid == (uint64_t)getpid()) { peer_stage[q] = (const char*)(uintptr_t)sl.raw; continue; }   // a thread of this process
+            hipIpcMemHandle_t hq;
+            memcpy(&hq, sl.handle, 64);
+            void* base = nullptr;
+            const double t_open = now_s();
+            PEER_DBG("mapping the staging buffer of rank %d (%llu bytes)", q, (unsigned long long)sl.stage_bytes);
+            const hipError_t err = hipIpcOpenMemHandle(&base, hq, hipIpcMemLazyEnablePeerAccess);
+            if (err != hipSuccess) { error = "hipIpcOpenMemHandle(rank " + std::to_string(q) + ") failed: " + hipGetErrorString(err); return false; }
+            if (now_s() - t_open > 0.25)                           // an anomaly worth a line: normally milliseconds
+                fprintf(stderr, "[zk_shard] rank %d: peer-copy transport: mapping the staging buffer of rank %d took %.2f s\n", rank, q, now_s() - t_open);
+            peer_stage[q] = (const char*)base;
+            opened[q] = true;
+        }
+        return true;
     }
     void close() {
-        for (int q = 0; q < kMaxWorld; ++q) {
-            for (auto& o : opened[q]) (void)hipIpcCloseMemHandle(o.base);
-            opened[q].clear();
-        }
+        for (int q = 0; q < kMaxWorld; ++q)
+            if (opened[q]) { (void)hipIpcCloseMemHandle((void*)peer_stage[q]); opened[q] = false; }
+        if (stage) { (void)hipFree(stage); stage = nullptr; }
         if (page) munmap(page, sizeof(Page));
         page = nullptr;
     }
@@ -140,62 +178,39 @@ struct PeerTransport {
         }
         return 0;
     }
-    bool fill(Entry& e, const void* ptr) {
-        memset(&e, 0, sizeof e);
-        e.raw = (uint64_t)(uintptr_t)ptr;
-        e.pid = (uint64_t)getpid();
-        if (!ptr) return true;
-        hipDeviceptr_t base = nullptr;
-        size_t size = 0;
-        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) != hipSuccess) { error = "hipMemGetAddressRange failed for a send buffer"; return false; }
-        e.offset = (uint64_t)((const char*)ptr - (const char*)base);
-        for (auto& m : mine)
-            if (m.base == base) { memcpy(e.handle, &m.handle, 64); return true; }
-        Mine m{base, {}};
-        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
-        if (hipIpcGetMemHandle(&m.handle, base) != hipSuccess) { error = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(hipGetLastError()); return false; }
-        mine.push_back(m);
-        memcpy(e.handle, &m.handle, 64);
-        return true;
-    }
-    const void* resolve(int q, const Entry& e) {
-        if (e.pid == (uint64_t)getpid()) return (const void*)(uintptr_t)e.raw;        // a thread of this process
-        for (auto& o : opened[q])
-            if (!memcmp(o.handle, e.handle, 64)) return (const char*)o.base + e.offset;
-        hipIpcMemHandle_t h;
-        memcpy(&h, e.handle, 64);
-        void* base = nullptr;
-        const hipError_t err = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
-        if (err != hipSuccess) { error = std::string("hipIpcOpenMemHandle(rank ") + std::to_string(q) + ") failed: " + hipGetErrorString(err); return nullptr; }
-        Opened o;
-        memcpy(o.handle, e.handle, 64);
-        o.base = base;
-        opened[q].push_back(o);
-        return (const char*)base + e.offset;
-    }
-    // send[p] != nullptr for every p (all-to-all) or one pointer for everybody (all-gather: send_all)
+    // all-to-all: send[p] (words) goes to rank p, recv[q] comes from rank q; all-gather: send_all to everybody, recv_all[q * words ..] from q
     int exchange(const uint32_t* const* send, const uint32_t* send_all, uint32_t* const* recv, uint32_t* recv_all, size_t words, hipStream_t st) {
-        if (!page) { error = "peer-copy transport is closed"; return 1; }
-        if (hipStreamSynchronize(st) != hipSuccess) { error = "hipStreamSynchronize before a peer-copy collective failed"; return 1; }
+        if (!page || !stage) { error = "peer-copy transport is closed"; return 1; }
+        const size_t need = (send ? (size_t)G : (size_t)1) * words * 4;
+        if (need > stage_bytes) { error = "peer-copy transport: a collective of " + std::to_string(need) + " bytes exceeds the staging buffer (" + std::to_string(stage_bytes) + ")"; return 1; }
         const uint64_t k = ++seq;
+        PEER_DBG("collective #%llu (%s, %zu words): staging", (unsigned long long)k, send ? "all-to-all" : "all-gather", words);
+        // 1. my pieces into my staging buffer (stream-ordered behind their producers), then the stream drained
+        for (int p = 0; p < (send ? G : 1); ++p) {
+            const void* src = send ? (const void*)send[p] : (const void*)send_all;
+            if (hipMemcpyAsync((char*)stage + (size_t)p * words * 4, src, words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { error = "staging copy failed"; return 1; }
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) { error = std::string("hipStreamSynchronize before a peer-copy collective failed: ") + hipGetErrorString(hipGetLastError()); return 1; }
         Slot& my = page->slot[rank];
-        for (int p = 0; p < G; ++p)
-            if (!fill(my.to[p], send ? (const void*)send[p] : (const void*)send_all)) return 1;
+        my.words = words;
         __atomic_store_n(&my.posted, k, __ATOMIC_RELEASE);
+        PEER_DBG("#%llu: posted", (unsigned long long)k);
+        // 2. pull my piece from every peer's staging buffer
         for (int i = 0; i < G; ++i) {
             const int q = (rank + i) % G;                          // every rank starts with a different peer
-            if (wait_word(&page->slot[q].posted, k, q, "the send pointers")) return 1;
-            Entry e;
-            memcpy(&e, &page->slot[q].to[rank], sizeof e);
-            const void* src = q == rank ? (const void*)(uintptr_t)e.raw : resolve(q, e);
-            if (!src) return 1;
+            if (wait_word(&page->slot[q].posted, k, q, "the pieces")) return 1;
+            if (page->slot[q].words != words) { error = "peer-copy transport: rank " + std::to_string(q) + " runs a collective of another size (the ranks diverged)"; return 1; }
+            const char* src = peer_stage[q] + (send ? (size_t)rank * words * 4 : (size_t)0);
             void* dst = recv ? (void*)recv[q] : (void*)(recv_all + (size_t)q * words);
-            if (dst != src && hipMemcpyAsync(dst, src, words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { error = "peer copy failed"; return 1; }
+            if (hipMemcpyAsync(dst, src, words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { error = "peer copy failed"; return 1; }
         }
+        PEER_DBG("#%llu: copies enqueued, synchronising", (unsigned long long)k);
         if (hipStreamSynchronize(st) != hipSuccess) { error = std::string("peer copies failed: ") + hipGetErrorString(hipGetLastError()); return 1; }
+        // 3. nobody overwrites a staging buffer before every peer has read it
         __atomic_store_n(&my.done, k, __ATOMIC_RELEASE);
         for (int q = 0; q < G; ++q)
             if (wait_word(&page->slot[q].done, k, q, "the end of the copies")) return 1;
+        PEER_DBG("#%llu: complete", (unsigned long long)k);
         return 0;
     }
 };

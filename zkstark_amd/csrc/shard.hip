@@ -26,6 +26,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <array>
 #include <chrono>
 #include <cstdio>
@@ -973,7 +974,7 @@ int zk_shard_destroy(zk_shard* s) {
         if (s->xcomm) { (void)s->rccl->CommAbort(s->xcomm); s->xcomm = nullptr; }
         if (s->comm) { (void)s->rccl->CommAbort(s->comm); s->comm = nullptr; }
     }
-    if (s->failed && !s->rccl && collectives(s)) {
+    if (s->failed && !s->rccl && !s->peer && collectives(s)) {      // (the peer-copy transport is host-synchronous: nothing of it ever waits on a stream)
         // a caller's transport cannot be aborted from here: if one of its collectives is still pending, waiting for the
         // streams (or freeing device memory, which synchronises the device) would hang for ever
         bool pending = false;
@@ -983,7 +984,6 @@ int zk_shard_destroy(zk_shard* s) {
             fprintf(stderr, "[zk_shard] rank %d of %d: a collective of the caller's transport is still pending after a failure; "
                             "the prover's streams and device buffers are leaked instead of waited for\n", s->rank, s->G);
             s->board.close();
-            if (s->peer) { if (s->peer->page) munmap(s->peer->page, sizeof(PeerTransport::Page)); delete s->peer; }   // mapped peer memory is leaked with the rest
             delete s;
             return ZK_OK;
         }
@@ -1102,8 +1102,11 @@ int zk_shard_create(int device, int rank, int world, const uint8_t* id, const zk
         snprintf(pname, sizeof pname, "/zkstark_amd_p%02x%02x%02x%02x%02x%02x%02x%02x", dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], dg[6], dg[7]);
         s->peer = new (std::nothrow) PeerTransport();
         if (!s->peer) return bail(fail(ZK_ERR_NOMEM, "out of host memory"));
-        if (!s->peer->open(pname, rank, world, s->timeout_s))
+        // staging: the largest collective is a layer-0 all-to-all, G pieces of N / G^2 words = this rank's whole shard of f
+        const size_t stage_bytes = std::max<size_t>(((size_t)1 << (log_n + log_b - lg)) * 4, (size_t)1 << 20);
+        if (!s->peer->open(pname, rank, world, s->timeout_s, stage_bytes))
             return bail(fail(ZK_ERR_HIP, "zk_shard_create: peer-copy transport (rank %d of %d): %s", rank, world, s->peer->error.c_str()));
+        s->device_bytes += (double)s->peer->stage_bytes;
         s->tp.user = s;
         s->tp.all_to_all = peer_all_to_all;
         s->tp.all_gather = peer_all_gather;
