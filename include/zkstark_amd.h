@@ -351,11 +351,12 @@ typedef struct zk_shard_options {   /* zero = default (struct_size excepted) */
                                    cp over a rank's block is recomputed from the block of f the rank received for the
                                    commitment of f, inside the leaf hashing -- no exchange for cp (zk_shard_plan_info.cp_from_f) */
     double timeout_s;           /* bound of every host-side wait on a peer; 0 = environment ZK_SHARD_TIMEOUT_S, else 120 s */
-    int peer_copy;              /* transport == NULL: instead of RCCL, the built-in PEER-COPY transport (csrc/peer.hpp): the ranks of one
-                                   node publish IPC handles of their send buffers on a shared-memory page and every rank pulls its
-                                   pieces with device-to-device copies.  Host-synchronous (implies plain_collectives); `id` is any 128
-                                   bytes shared by the ranks.  The rung below "RCCL, plain collectives": for a node where no
-                                   communicator can be formed (bench.py --gpus N falls back to it) */
+    int peer_copy;              /* transport == NULL: instead of RCCL, the built-in PEER-COPY transport (csrc/peer.hpp): every rank of
+                                   the node publishes the IPC handle of ONE staging buffer on a shared-memory page at creation, a
+                                   collective copies its pieces there and every rank pulls its piece with a device-to-device copy.
+                                   Host-synchronous (implies plain_collectives); `id` is any 128 bytes shared by the ranks.  The rung
+                                   below "RCCL, plain collectives": for a node where no communicator can be formed (bench.py --gpus N
+                                   falls back to it) */
     int reserved;
 } zk_shard_options;
 typedef struct zk_shard_stats {
