@@ -329,17 +329,17 @@ def worker_rendezvous(R):
 # ---- --plan-only: the layout of the sharded run and an estimate written down BEFORE the run (no GPU) -------------------------
 # One-GPU proxies behind the estimate (every figure an ESTIMATE until a multi-GPU node has run the line):
 #   * per-rank device work with the ranks as threads of one process sharing ONE MI355X, total / G
-#     (profiles/r05_shard_threads_timing.txt: weak shape, 2^24 elements per rank; profiles/r05_shard_threads_strong.txt: one
+#     (profiles/r06_shard_threads_timing.txt: weak shape, 2^24 elements per rank; profiles/r06_shard_threads_strong.txt: one
 #     2^24 proof over G ranks); the harness's exchanges are device copies, so these hold NO link time;
 #   * xGMI: 7 links x ~153 GB/s per GPU, point to point (MI355X_MICROARCH.md): in an all-to-all every pair has its own link,
 #     so a rank's exchange of `piece` bytes per peer takes piece / 153 GB/s however many peers there are; ~25 us of latency
 #     per collective (RCCL launch + handshake; not measured here);
 #   * the replicated tail, the decommitment and the size-n inverse transform do not shrink with G.
 PROXY = {
-    "source": ["profiles/r05_shard_threads_timing.txt", "profiles/r05_shard_threads_strong.txt", "profiles/r05_shard_min_layer.txt"],
+    "source": ["profiles/r06_shard_threads_timing.txt", "profiles/r06_shard_threads_strong.txt", "profiles/r05_shard_min_layer.txt"],
     # summed device work of all ranks / G, ms: a LOWER bound of a rank's critical path (no link time, no peer skew)
-    "weak_ms_per_rank": {2: 5.6, 4: 6.0, 8: 5.7}, "single_gpu_ms_2e24": 5.7,
-    "strong_ms_per_rank": {2: 3.2, 4: 1.9, 8: 1.2},
+    "weak_ms_per_rank": {2: 5.7, 4: 5.7, 8: 5.7}, "single_gpu_ms_2e24": 5.7,
+    "strong_ms_per_rank": {2: 3.2, 4: 2.0, 8: 1.3},
     "replicated_tail_ms": {2: 0.79, 4: 0.63, 8: 0.53}, "decommit_ms": 0.045,
     "xgmi_link_GBps": 153.0, "collective_latency_us": 25.0,
 }
