@@ -56,3 +56,19 @@ def test_root_board_under_sanitizers(tmp_path, san):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "board ok" in out.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_peer_copy_protocol_under_sanitizers(tmp_path, san):
+    """The peer-copy transport of the sharded prover (csrc/peer.hpp, round 6) with host memory standing in for the GPU (the device
+    runtime is a policy of the transport; -DZK_PEER_NO_HIP): 1-8 ranks as threads, thousands of all-to-alls and all-gathers of
+    changing sizes with skewed timing and every word checked, a collective larger than the staging buffer, a rank that leaves
+    (its peers return at once, naming it), a rank that never comes (bounded; nothing left in /dev/shm).  Under ThreadSanitizer the
+    release / acquire pairs on the shared page are mirrored on process-wide keys (every rank maps the page at its own address);
+    dropping the second meeting of a collective makes this test fail with data races (checked by hand in round 6)."""
+    exe = str(tmp_path / "peer_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", f"-fsanitize={san}", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "peer_check.cpp"), "-o", exe, "-lrt"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr[-4000:]
+    assert "peer transport protocol ok" in out.stdout

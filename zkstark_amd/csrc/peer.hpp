@@ -14,7 +14,9 @@
 //   3. hipStreamSynchronize; release-store done = k; wait done[q] >= k for every q (nobody refills its staging buffer earlier).
 #pragma once
 #include <fcntl.h>
+#ifndef ZK_PEER_NO_HIP
 #include <hip/hip_runtime.h>
+#endif
 #include <sched.h>
 #include <stdint.h>
 #include <string.h>
@@ -38,7 +40,52 @@
 namespace zk {
 namespace impl {
 
-struct PeerTransport {
+// ThreadSanitizer follows synchronisation by ADDRESS, and every rank maps the shared page at an address of its own: under TSan (the
+// ranks are threads of one test process) the release / acquire pairs on the page are therefore mirrored on process-wide keys, one per
+// (rank, word), so that the tool sees the happens-before the shared physical page provides.  No code in a normal build.
+#if defined(__SANITIZE_THREAD__)
+extern "C" void __tsan_acquire(void* addr);
+extern "C" void __tsan_release(void* addr);
+inline char* peer_tsan_key(int r, int word) { static char k[32][4]; return &k[r & 31][word & 3]; }
+#define PEER_TSAN_RELEASE(r, w) __tsan_release(::zk::impl::peer_tsan_key((r), (w)))
+#define PEER_TSAN_ACQUIRE(r, w) __tsan_acquire(::zk::impl::peer_tsan_key((r), (w)))
+#else
+#define PEER_TSAN_RELEASE(r, w) do { } while (0)
+#define PEER_TSAN_ACQUIRE(r, w) do { } while (0)
+#endif
+
+// What the transport needs from the device runtime, as a policy: the protocol on the shared page (everything below) is plain host
+// code and runs under ThreadSanitizer with host memory standing in for the GPU (tests/peer_check.cpp: -DZK_PEER_NO_HIP).
+#ifndef ZK_PEER_NO_HIP
+struct PeerHipOps {
+    using stream_t = hipStream_t;
+    static bool alloc(void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; }
+    static void release(void* p) { (void)hipFree(p); }
+    static bool export_handle(void* p, uint8_t out[64], std::string& err) {
+        hipIpcMemHandle_t h;
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+        if (hipIpcGetMemHandle(&h, p) != hipSuccess) { err = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(hipGetLastError()); return false; }
+        memcpy(out, &h, 64);
+        return true;
+    }
+    static void* import_handle(const uint8_t in[64], std::string& err) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, in, 64);
+        void* base = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { err = std::string("hipIpcOpenMemHandle failed: ") + hipGetErrorString(e); return nullptr; }
+        return base;
+    }
+    static void unimport(void* p) { (void)hipIpcCloseMemHandle(p); }
+    static bool copy(void* dst, const void* src, size_t bytes, stream_t st) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess; }
+    static bool sync(stream_t st) { return hipStreamSynchronize(st) == hipSuccess; }
+    static const char* last_error() { return hipGetErrorString(hipGetLastError()); }
+};
+#endif
+
+template <class Ops>
+struct PeerTransportT {
+    using stream_t = typename Ops::stream_t;
     static constexpr int kMaxWorld = 32;
     static constexpr uint64_t kMagic = 0x7a6b706565723032ull;      // "zkpeer02"
     struct Slot {
@@ -117,13 +164,11 @@ struct PeerTransport {
         if (!all) return false;
         // the staging buffer: allocate, publish, map the peers'
         stage_bytes = (bytes + 255) & ~(size_t)255;
-        if (hipMalloc((void**)&stage, stage_bytes) != hipSuccess) { error = "hipMalloc of the staging buffer failed"; stage = nullptr; return false; }
+        if (!Ops::alloc((void**)&stage, stage_bytes)) { error = "allocation of the staging buffer failed"; stage = nullptr; return false; }
         Slot& my = page->slot[rank];
-        hipIpcMemHandle_t h;
-        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
-        if (hipIpcGetMemHandle(&h, stage) != hipSuccess) { error = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(hipGetLastError()); return false; }
-        memcpy(my.handle, &h, 64);
+        if (!Ops::export_handle(stage, my.handle, error)) return false;
         my.stage_bytes = stage_bytes; my.raw = (uint64_t)(uintptr_t)stage; my.pid = (uint64_t)getpid();
+        PEER_TSAN_RELEASE(rank, 2);
         __atomic_store_n(&my.ready, 1u, __ATOMIC_RELEASE);
         for (int q = 0; q < G; ++q) {
             Slot& sl = page->slot[q];
@@ -131,14 +176,13 @@ struct PeerTransport {
                 if (now_s() - t0 > timeout_s) { error = "rank " + std::to_string(q) + " never published its staging buffer (peer-copy transport)"; return false; }
                 sched_yield();
             }
+            PEER_TSAN_ACQUIRE(q, 2);
             if (q == rank || sl.pid == (uint64_t)getpid()) { peer_stage[q] = (const char*)(uintptr_t)sl.raw; continue; }   // a thread of this process
-            hipIpcMemHandle_t hq;
-            memcpy(&hq, sl.handle, 64);
-            void* base = nullptr;
             const double t_open = now_s();
             PEER_DBG("mapping the staging buffer of rank %d (%llu bytes)", q, (unsigned long long)sl.stage_bytes);
-            const hipError_t err = hipIpcOpenMemHandle(&base, hq, hipIpcMemLazyEnablePeerAccess);
-            if (err != hipSuccess) { error = "hipIpcOpenMemHandle(rank " + std::to_string(q) + ") failed: " + hipGetErrorString(err); return false; }
+            std::string why;
+            void* base = Ops::import_handle(sl.handle, why);
+            if (!base) { error = "mapping the staging buffer of rank " + std::to_string(q) + ": " + why; return false; }
             if (now_s() - t_open > 0.25)                           // an anomaly worth a line: normally milliseconds
                 fprintf(stderr, "[zk_shard] rank %d: peer-copy transport: mapping the staging buffer of rank %d took %.2f s\n", rank, q, now_s() - t_open);
             peer_stage[q] = (const char*)base;
@@ -148,8 +192,8 @@ struct PeerTransport {
     }
     void close() {
         for (int q = 0; q < kMaxWorld; ++q)
-            if (opened[q]) { (void)hipIpcCloseMemHandle((void*)peer_stage[q]); opened[q] = false; }
-        if (stage) { (void)hipFree(stage); stage = nullptr; }
+            if (opened[q]) { Ops::unimport((void*)peer_stage[q]); opened[q] = false; }
+        if (stage) { Ops::release(stage); stage = nullptr; }
         if (page) munmap(page, sizeof(Page));
         page = nullptr;
     }
@@ -179,7 +223,7 @@ struct PeerTransport {
         return 0;
     }
     // all-to-all: send[p] (words) goes to rank p, recv[q] comes from rank q; all-gather: send_all to everybody, recv_all[q * words ..] from q
-    int exchange(const uint32_t* const* send, const uint32_t* send_all, uint32_t* const* recv, uint32_t* recv_all, size_t words, hipStream_t st) {
+    int exchange(const uint32_t* const* send, const uint32_t* send_all, uint32_t* const* recv, uint32_t* recv_all, size_t words, stream_t st) {
         if (!page || !stage) { error = "peer-copy transport is closed"; return 1; }
         const size_t need = (send ? (size_t)G : (size_t)1) * words * 4;
         if (need > stage_bytes) { error = "peer-copy transport: a collective of " + std::to_string(need) + " bytes exceeds the staging buffer (" + std::to_string(stage_bytes) + ")"; return 1; }
@@ -188,32 +232,41 @@ struct PeerTransport {
         // 1. my pieces into my staging buffer (stream-ordered behind their producers), then the stream drained
         for (int p = 0; p < (send ? G : 1); ++p) {
             const void* src = send ? (const void*)send[p] : (const void*)send_all;
-            if (hipMemcpyAsync((char*)stage + (size_t)p * words * 4, src, words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { error = "staging copy failed"; return 1; }
+            if (!Ops::copy((char*)stage + (size_t)p * words * 4, src, words * 4, st)) { error = "staging copy failed"; return 1; }
         }
-        if (hipStreamSynchronize(st) != hipSuccess) { error = std::string("hipStreamSynchronize before a peer-copy collective failed: ") + hipGetErrorString(hipGetLastError()); return 1; }
+        if (!Ops::sync(st)) { error = std::string("stream synchronisation before a peer-copy collective failed: ") + Ops::last_error(); return 1; }
         Slot& my = page->slot[rank];
         my.words = words;
+        PEER_TSAN_RELEASE(rank, 0);
         __atomic_store_n(&my.posted, k, __ATOMIC_RELEASE);
         PEER_DBG("#%llu: posted", (unsigned long long)k);
         // 2. pull my piece from every peer's staging buffer
         for (int i = 0; i < G; ++i) {
             const int q = (rank + i) % G;                          // every rank starts with a different peer
             if (wait_word(&page->slot[q].posted, k, q, "the pieces")) return 1;
+            PEER_TSAN_ACQUIRE(q, 0);
             if (page->slot[q].words != words) { error = "peer-copy transport: rank " + std::to_string(q) + " runs a collective of another size (the ranks diverged)"; return 1; }
             const char* src = peer_stage[q] + (send ? (size_t)rank * words * 4 : (size_t)0);
             void* dst = recv ? (void*)recv[q] : (void*)(recv_all + (size_t)q * words);
-            if (hipMemcpyAsync(dst, src, words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { error = "peer copy failed"; return 1; }
+            if (!Ops::copy(dst, src, words * 4, st)) { error = "peer copy failed"; return 1; }
         }
         PEER_DBG("#%llu: copies enqueued, synchronising", (unsigned long long)k);
-        if (hipStreamSynchronize(st) != hipSuccess) { error = std::string("peer copies failed: ") + hipGetErrorString(hipGetLastError()); return 1; }
+        if (!Ops::sync(st)) { error = std::string("peer copies failed: ") + Ops::last_error(); return 1; }
         // 3. nobody overwrites a staging buffer before every peer has read it
+        PEER_TSAN_RELEASE(rank, 1);
         __atomic_store_n(&my.done, k, __ATOMIC_RELEASE);
-        for (int q = 0; q < G; ++q)
+        for (int q = 0; q < G; ++q) {
             if (wait_word(&page->slot[q].done, k, q, "the end of the copies")) return 1;
+            PEER_TSAN_ACQUIRE(q, 1);
+        }
         PEER_DBG("#%llu: complete", (unsigned long long)k);
         return 0;
     }
 };
+
+#ifndef ZK_PEER_NO_HIP
+using PeerTransport = PeerTransportT<PeerHipOps>;
+#endif
 
 }  // namespace impl
 }  // namespace zk
