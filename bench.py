@@ -411,6 +411,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("ZK_BENCH_TEST_WORKER_SLEEP"):         # tests/test_bench_cli.py: a worker that is busy when SIGTERM arrives above it
         time.sleep(float(os.environ["ZK_BENCH_TEST_WORKER_SLEEP"]))
+    if os.environ.get("ZK_BENCH_TEST_WORKER_SCRIPT") and os.environ.get("ZK_BENCH_WORKER") == "1":
+        # tests/test_bench_cli.py: the supervisor's state machine without a GPU -- the k-th worker of this rank exits with the k-th
+        # scripted code ("7@1" first reports rung 1 as reached, as a real worker does before it dies there)
+        script = os.environ["ZK_BENCH_TEST_WORKER_SCRIPT"].split(",")
+        step = script[min(int(os.environ.get("ZK_BENCH_ATTEMPT", "0")) + int(os.environ.get("ZK_BENCH_TEST_STALE_SEEN", "0")), len(script) - 1)]
+        code, _, reached = step.partition("@")
+        print(f"[bench-test] worker: rung {os.environ.get('ZK_BENCH_RUNG')}, attempt {os.environ.get('ZK_BENCH_ATTEMPT')}, generation "
+              f"{os.environ.get('ZK_BENCH_GEN')}: exiting with {step}", file=sys.stderr, flush=True)
+        if reached and os.environ.get("ZK_BENCH_STATUS"):
+            with open(os.environ["ZK_BENCH_STATUS"], "w") as f:
+                f.write(reached)
+        sys.exit(int(code))
     if world != args.gpus:
         args.gpus = world
     # before anything initialises HIP / HSA: dmabuf IPC for RCCL's peer-to-peer buffers, loopback for the gloo control plane

@@ -215,6 +215,7 @@ def supervise():
             if code == STALE_GENERATION and stale_restarts < 8:
                 # the peers had already moved on when this worker arrived: join them, the ladder does not advance
                 stale_restarts += 1
+                os.environ["ZK_BENCH_TEST_STALE_SEEN"] = str(stale_restarts)      # (only read by the scripted worker of the tests)
                 gen = max(gen + 1, _current_generation(tag))
                 continue
             try:

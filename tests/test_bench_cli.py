@@ -252,3 +252,33 @@ def test_bench_two_ranks_sharing_the_gpu_on_the_peer_copy_rung(env_extra, want_n
     st = rec["strong_2e20"]
     assert st["parity"]["equal"] is True and st["ranks_agree"] is True and st["shard"]["peer_copy"] == 1
     assert rec["lde_commit_sharded"]["root_stable"] is True
+
+
+@pytest.mark.parametrize("script,want_rc,want_rungs,want_generations", [
+    ("0", 0, ["0"], 1),                                   # the first worker prints the line
+    ("3", 3, ["0"], 1),                                   # not enough GPUs: nothing another transport would change
+    ("4", 4, ["0"], 1),                                   # a proof that differs: never retried
+    ("8,8,0", 0, ["0", "0", "0"], 3),                     # the peers had moved on (twice): rejoin them, the ladder does not advance
+    ("7,0", 0, ["0", "0"], 2),                            # died before it reached a rung: the same rung again
+    ("7@0,7@1,7@2,0", 0, ["0", "1", "2", "3"], 4),        # a hang on every rung in turn: RCCL chunked -> RCCL plain -> peer copy -> torch
+    ("7@0,7@1,7@2,7@3", 7, ["0", "1", "2", "3"], 4),      # the last rung fails too: the run ends with that code, no fifth worker
+])
+def test_bench_supervisor_state_machine(script, want_rc, want_rungs, want_generations):
+    """bench_multi.supervise() with scripted workers (no GPU, no torch): which rung each fresh worker starts on, that stale
+    generations do not advance the ladder, that codes 3 / 4 end the run, and that the run's files under /tmp are removed whatever
+    happened (every branch of the supervisor is exercised here or by a GPU rehearsal)."""
+    import glob
+    import re
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ZK_BENCH_FORCE_SHARDED="1", ZK_BENCH_TEST_WORKER_SCRIPT=script)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, env=env)
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == want_rc, (p.returncode, err[-2000:])
+    rungs = re.findall(r"\[bench-test\] worker: rung (\d+)", err)
+    gens = re.findall(r"generation (\d+):", err)
+    assert rungs == want_rungs, err[-2000:]
+    assert len(set(gens)) == want_generations and gens == sorted(gens, key=int), gens
+    assert out.strip() == ""                                   # scripted workers print no line
+    # the run's files are named after the supervisor's PARENT (the launcher, here this test process) and the rendezvous port
+    assert [f for f in glob.glob("/tmp/zkbench_*") if f"_{os.getpid()}_0" in f] == []
