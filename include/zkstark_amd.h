@@ -139,6 +139,16 @@ int zk_ctx_set_hash(zk_ctx *ctx, int hash_kind);
  * identical for every setting. */
 int zk_ctx_set_host_levels(zk_ctx *ctx, uint32_t top_log, uint32_t tail_log);
 int zk_ctx_get_host_levels(const zk_ctx *ctx, uint32_t *top_log, uint32_t *tail_log);
+/* Early launch (round 6).  A proof is a chain of commitments: digests to the host, root into the channel, challenge out, the next
+ * layer's launches (prover.rs:198-225).  With on != 0, zk_prove* enqueues the fold + commit launches of the NEXT FRI round before it
+ * waits for the current commitment, behind a command-processor wait on a host word (hipStreamWaitValue32), and releases them with
+ * one store once the challenge is drawn: the launch call and ~2.5 us of dispatch latency per commitment leave the critical path.
+ * Results are identical either way.  Off by default: measured inside one build at nothing outside the spread for a 2^24 proof,
+ * -1.5 % for a 2^20 proof, -5 % at the reference's own size (profiles/r06_ab_early_launch.txt); worth switching on for small
+ * domains proved one at a time.  Contexts that share a GPU (zk_prove_many) should leave it off: a stream that waits on its gate
+ * holds the hardware queue another context's stream may be mapped to.  zk_ctx_get_early_launch: 1 when on AND supported. */
+int zk_ctx_set_early_launch(zk_ctx *ctx, int on);
+int zk_ctx_get_early_launch(const zk_ctx *ctx);
 /* The HIP stream every stage is enqueued on (hipStream_t). */
 void *zk_ctx_stream(zk_ctx *ctx);
 

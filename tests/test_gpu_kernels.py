@@ -810,3 +810,49 @@ def test_maximum_domain_2e30(zk):
     p.verify(strict=True)
     with pytest.raises(zk.ZkError):
         zk.Context(28, 3)                                    # n * B = 2^31 does not divide P - 1 = 3 * 2^30
+
+
+@pytest.mark.parametrize("log_n,log_b,hash_name", [(4, 3, "sha256"), (10, 3, "sha256"), (13, 2, "sha256"), (17, 3, "sha256"), (12, 3, "field"), (18, 1, "sha256")])
+def test_early_launch_gives_the_same_proof(zk, orc, log_n, log_b, hash_name):
+    """zk_ctx_set_early_launch: the next FRI round's launches enqueued before the current commitment is waited for, released by one
+    store once the challenge is drawn (a command-processor wait on a host word; the round's constant read from pinned host memory).
+    Same bytes as the oracle, proof after proof, with the switch flipped between proofs and with several queries."""
+    if hash_name == "field":
+        orc.set_hash(orc.HASH_FIELD)
+    try:
+        want = orc.prove(log_n, log_b, want_vectors=False)
+    finally:
+        orc.set_hash(orc.HASH_SHA256)
+    with zk.Context(log_n, log_b, hash=hash_name) as ctx:
+        ctx.trace_upload(zk.trace_fibsq((1 << log_n) - 1))
+        supported = ctx.set_early_launch(True)
+        if not supported:
+            pytest.skip("the device has no stream memory operations")
+        for _ in range(3):
+            p = ctx.prove()
+            assert p.data == want.proof and p.state == want.state
+        ctx.set_early_launch(False)
+        p = ctx.prove()
+        assert p.data == want.proof
+        ctx.set_early_launch(True)
+        p = ctx.prove()
+        assert p.data == want.proof and p.state == want.state
+        p.verify(strict=True) if hash_name == "sha256" else p.verify()
+
+
+def test_early_launch_survives_a_failed_proof(zk, orc):
+    """A proof that ends with an error while the next round's launches sit behind the gate (a trace that breaks the recurrence:
+    prover.rs:238 fails at the last layer) must release them: the context proves correctly afterwards and nothing hangs."""
+    want = orc.prove(12, 3, want_vectors=False)
+    good = zk.trace_fibsq((1 << 12) - 1)
+    bad = good.copy()
+    bad[1000] = (int(bad[1000]) + 1) % P
+    with zk.Context(12, 3) as ctx:
+        if not ctx.set_early_launch(True):
+            pytest.skip("the device has no stream memory operations")
+        for _ in range(2):
+            with pytest.raises(zk.ZkError):
+                ctx.prove(bad)
+            p = ctx.prove(good)
+            assert p.data == want.proof and p.state == want.state
+        ctx.sync()

@@ -127,6 +127,8 @@ SYMBOLS = {
     "zk_ctx_set_host_levels": (_int, [_vp, _u32, _u32]),
     "zk_ctx_get_host_levels": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "zk_ctx_set_queries": (_int, [_vp, _u32]),
+    "zk_ctx_set_early_launch": (_int, [_vp, _int]),
+    "zk_ctx_get_early_launch": (_int, [_vp]),
     "zk_verify_queries": (_int, [_vp, _sz, _vp, _u32, _u32, _u32, _int, _u32]),
     "zk_proof_data_len_queries": (_sz, [_u32, _u32, _u32]),
     "zk_ctx_stream": (_vp, [_vp]),

@@ -539,6 +539,7 @@ struct PlainSrc {
 struct FoldSrc {       // FRI layer r+1 = fold(layer r, beta): prover.rs:198-211 + :214
     FoldArgs a;
     using Raw = FoldRaw;
+    __device__ __forceinline__ void prepare() { if (a.dyn) a.c_mont = *a.dyn; }   // early launch: the challenge arrived after the enqueue
     __device__ __forceinline__ Raw fetch(size_t pos) const { return fold_fetch(a, pos); }
     __device__ __forceinline__ uint32_t finish(const Raw& r, size_t pos) const { uint32_t v = fold_finish(a, r); a.out[pos] = v; return v; }
     __device__ __forceinline__ uint32_t load(size_t pos) const { return finish(fetch(pos), pos); }
@@ -622,6 +623,11 @@ struct InterleaveSrc { // leaves arrive as 2^log_parts cyclic pieces of 2^log_cn
     __device__ __forceinline__ uint32_t finish(const Raw& r, size_t) const { return r; }
 };
 
+// Sources whose constants may arrive after the launch was enqueued have a prepare(); every kernel calls it on its own copy of the
+// source before the first element is produced.
+template <class S> __device__ __forceinline__ auto src_prepare(S& s, int) -> decltype(s.prepare(), void()) { s.prepare(); }
+template <class S> __device__ __forceinline__ void src_prepare(S&, long) {}
+
 constexpr int kMerkleThreads = 256;
 constexpr uint32_t kMerkleMaxK = 4;
 
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(kMerkleThreads) void merkle_subtree_kernel(SRC src,
     // measured 6.19 ms per 2^24 proof against 6.07 ms for this kernel, profiles/r03_ab_subtree_heap.txt: SHA-256 as
     // compiled does not issue faster with more resident waves, and the second inlined copy of the hash costs more.)
     extern __shared__ __attribute__((aligned(16))) uint4 stage[];
+    src_prepare(src, 0);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const size_t gwave = (size_t)blockIdx.x * (kMerkleThreads / 64) + wave;
     // first input of this wave; `off` = position of a chunk's first node at this depth (0 for a whole
@@ -786,6 +793,7 @@ template <class SRC, bool LEAF, int HASH>
 __global__ __launch_bounds__(kWgThreads) void merkle_wg_kernel(SRC src, uint32_t* nodes, uint32_t depth_in, uint32_t j,
                                                                MailArgs mail, size_t off, uint32_t j2, uint32_t lds_log) {
     extern __shared__ __attribute__((aligned(16))) uint4 lvl[];   // [2^lds_log][2], then the 16 KiB schedule exchange
+    src_prepare(src, 0);
     uint32_t* xch = reinterpret_cast<uint32_t*>(lvl + ((size_t)2 << lds_log));
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 1u << j;                                       // inputs of this workgroup in the current phase

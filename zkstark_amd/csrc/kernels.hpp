@@ -203,6 +203,10 @@ struct FoldArgs {
     uint32_t L;
     uint32_t inv2_mont;   // 1/2
     uint32_t c_mont;      // beta * w^(-2^r) / 2
+    // Early launch (zk_ctx_set_early_launch): when non-null the launch was enqueued BEFORE its challenge existed, behind a
+    // command-processor wait; c_mont is then read from here (pinned host memory, an ordinary cached load like a kernel argument:
+    // the scalar cache is invalidated at every dispatch) when a workgroup starts -- kernels.hip: FoldSrc::prepare
+    const uint32_t* dyn;
 };
 hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s, Profiler* prof = nullptr);
 

@@ -80,6 +80,16 @@ struct zk_ctx {
     // pick the wrong "last" workgroup and post wrong digests silently, so the next launch zeroes them first.
     bool counters_dirty = false;
     uint32_t mail_seq = 0;
+    uint32_t tree_seq[40] = {};         // the mailbox sequence number the commit launch of tree t posts with (mail_of)
+    // Early launch (zk_ctx_set_early_launch; docs/LOG.md round 6): the fold + commit launches of the NEXT FRI round are enqueued
+    // before the current commitment's digests are waited for, behind a command-processor wait on a host word (hipStreamWaitValue32);
+    // when the challenge is known the host stores the round's constant into a pinned parameter slot and releases the word.
+    bool early = false, early_ok = false, gate_pending = false;
+    uint32_t* h_gate = nullptr;         // pinned, coherent, device-mapped: word 0 = the gate
+    uint32_t* d_gate = nullptr;
+    uint32_t* h_dyn = nullptr;          // pinned: two parameter slots of 16 words (a slot is reused every second round)
+    uint32_t* d_dyn = nullptr;
+    uint32_t gate_seq = 0;
     // Host-finished pieces of the one-call prover (host_sha.hpp): the top `host_top` levels of every tree
     // with more than 2^host_top leaves, and whole FRI layers of <= 2^host_tail values (fold + tree).
     uint32_t host_top = 0, host_tail = 0;
@@ -177,6 +187,7 @@ MailArgs mail_of(zk_ctx* c, uint32_t tree, bool host, bool feed_tail = true) {
     }
     m.mailbox = c->d_mailbox;
     m.seq = ++c->mail_seq;
+    c->tree_seq[tree] = m.seq;
     m.counter = c->d_counter;
     m.top = host ? top_of(c, tree) : 0;
     if (feed_tail && m.top && c->host_tail && tree >= 1 && layer_log(c, tree) == c->host_tail + 1) {
@@ -213,9 +224,9 @@ int do_fold_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
     return ZK_OK;
 }
 
-int wait_mail(zk_ctx* c) {
+int wait_mail(zk_ctx* c, uint32_t seq) {
     double t0 = now_us();
-    int rc = wait_flag(c->h_mailbox, c->mail_seq, c->stream);
+    int rc = wait_flag(c->h_mailbox, seq, c->stream);
     c->t_wait += now_us() - t0;
     if (rc) c->counters_dirty = true;
     return rc;
@@ -223,8 +234,7 @@ int wait_mail(zk_ctx* c) {
 
 // Root posted by a whole-tree build.
 int read_root(zk_ctx* c, uint32_t tree, uint8_t out[32]) {
-    (void)tree;
-    int rc = wait_mail(c);
+    int rc = wait_mail(c, c->tree_seq[tree]);
     if (rc) return rc;
     digest_words_to_bytes(c->h_mailbox + kMailDigests, out);
     return ZK_OK;
@@ -251,7 +261,7 @@ int read_commit(zk_ctx* c, uint32_t tree, uint8_t root[32]) {
     const size_t cnt = (size_t)1 << H;
     uint32_t* nodes = stage_alloc(c, (2 * cnt - 1) * 8);
     if (!nodes) return fail(ZK_ERR_STATE, "host staging buffer exhausted");
-    int rc = wait_mail(c);
+    int rc = wait_mail(c, c->tree_seq[tree]);
     if (rc) return rc;
     double t0 = now_us();
     memcpy(nodes + 8 * (cnt - 1), c->h_mailbox + kMailDigests, cnt * 32);
@@ -312,6 +322,41 @@ int fri_round_commit(zk_ctx* c, uint32_t round, uint32_t beta_raw, uint8_t root[
     int rc = do_fold_commit(c, round, beta_raw);
     return rc ? rc : read_commit(c, 2 + round, root);
 }
+// ---- early launch of the next FRI round (zk_ctx_set_early_launch) --------------------------------------------------------------
+// Round r is folded and committed by the host thread once the layers are small (host_fold_commit): exactly the rounds whose INPUT
+// layer has at most 2^(host_tail + 1) values, provided some committed layer has that size to feed the host (mail_of).
+bool round_on_host(const zk_ctx* c, uint32_t round) {
+    return c->hash == 0 && c->host_top && c->host_tail && c->L >= c->host_tail + 1 && c->L - round <= c->host_tail + 1;
+}
+bool can_gate(const zk_ctx* c, uint32_t round) { return c->early && c->early_ok && !c->checks && round < c->R && !round_on_host(c, round); }
+// The launches of do_fold_commit(round), enqueued behind a wait on the gate word; their one challenge-dependent constant is read
+// from a parameter slot the host fills in release_gated_fold.
+int enqueue_gated_fold(zk_ctx* c, uint32_t round) {
+    FoldArgs a;
+    int rc = fold_args(c->dom, c->d_layers + c->layer_off[1 + round], c->d_layers + c->layer_off[2 + round], c->L - round, round, 0u, a);
+    if (rc) return rc;
+    ++c->gate_seq;
+    a.dyn = c->d_dyn + 16 * (c->gate_seq & 1u);
+    HIPCHK(hipStreamWaitValue32(c->stream, c->d_gate, c->gate_seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
+    c->gate_pending = true;                                  // from here on the stream is blocked until the word is stored
+    HIPCHK(launch_fold_merkle(a, c->d_trees + c->tree_off[2 + round], c->stream, prof_of(c), mail_of(c, 2 + round, true), c->hash));
+    return ZK_OK;
+}
+void release_gate(zk_ctx* c, uint32_t c_mont) {
+    c->h_dyn[16 * (c->gate_seq & 1u)] = c_mont;
+    __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE);   // after the parameter (x86 stores are ordered; the device reads both over PCIe)
+    c->gate_pending = false;
+}
+void release_gated_fold(zk_ctx* c, uint32_t round, uint32_t beta_raw) {
+    release_gate(c, to_mont(mulmod(beta_raw % P, c->dom->fold_k[round])));   // beta * w^(-2^r) / 2, as fold_args
+}
+// A proof that ends early (an error between the enqueue and the release) must not leave the stream blocked: the pending launches
+// run with a meaningless constant into this context's own buffers, which the next proof rebuilds.
+struct GateGuard {
+    zk_ctx* c;
+    ~GateGuard() { if (c->gate_pending) release_gate(c, 0u); }
+};
+
 void begin_proof(zk_ctx* c) {
     c->stage_used = 0; c->n_segs = 0; c->seg_words = 0; c->tail_log = 0; c->tail_have = false;
     c->t_wait = c->t_host_hash = c->t_launch = 0;
@@ -460,7 +505,7 @@ int open_launch(zk_ctx* c) {
 int open_wait(zk_ctx* c) {
     if (!c->open_pending) return ZK_OK;
     c->open_pending = false;
-    return wait_mail(c);
+    return wait_mail(c, c->mail_seq);
 }
 
 // generate_proof(channel) (prover.rs:9): everything is committed to, and every challenge drawn from, the
@@ -484,6 +529,7 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     c->info.public_last = c->last;
     c->pending_top = false;                               // a pending stand-alone tree top: every tree is rebuilt below
     begin_proof(c);
+    GateGuard gate_guard{c};                              // whatever happens below, the stream is not left behind a closed gate
     if ((rc = do_lde(c))) return rc;                      // prover.rs:60-70
     if (c->checks && ((rc = checks_alloc(c)) || (rc = check_interpolant(c)))) return rc;   // prover.rs:64-66
     if ((rc = do_merkle(c, 0, true))) return rc;          // prover.rs:81
@@ -493,13 +539,25 @@ int prove_resident(zk_ctx* c, Channel& ch) {
     uint32_t alpha[3];
     for (int i = 0; i < 3; ++i) alpha[i] = c->info.alpha_raw[i] = ch.get_u32();   // prover.rs:163-165
     if ((rc = do_compose_commit(c, alpha))) return rc;    // prover.rs:166-176 (composition fused into the leaf hashing)
+    if (can_gate(c, 0) && (rc = enqueue_gated_fold(c, 0))) return rc;   // early launch: round 0 queued before cp's digests are waited for
     if ((rc = read_commit(c, 1, root))) return rc;
     if (c->checks && (rc = check_degree(c, 1, (uint32_t)c->n - 1, "prover.rs:148-159/:169 (exact divisions, deg cp = n - 1)"))) return rc;
     ch.commit_hash(root);                                 // prover.rs:180
     memcpy(c->info.roots[1], root, 32);
     for (uint32_t r = 0; r < R; ++r) {                    // prover.rs:198-225
         uint32_t beta = c->info.beta_raw[r] = ch.get_u32();   // prover.rs:200
-        if ((rc = fri_round_commit(c, r, beta, root))) return rc;   // prover.rs:201-214 (fold fused into the leaf hashing)
+        // prover.rs:201-214 (fold fused into the leaf hashing); on the host once the layers are small and present there
+        if (c->gate_pending) {
+            release_gated_fold(c, r, beta);               // this round's launches were enqueued before the challenge existed
+            if (can_gate(c, r + 1) && (rc = enqueue_gated_fold(c, r + 1))) return rc;   // ... and so are the next round's, now
+            if ((rc = read_commit(c, 2 + r, root))) return rc;
+        } else if (c->tail_have && c->tail_log == c->L - r && c->L - r - 1 <= c->host_tail) {
+            if ((rc = host_fold_commit(c, r, beta, root))) return rc;
+        } else {
+            if ((rc = do_fold_commit(c, r, beta))) return rc;
+            if (can_gate(c, r + 1) && (rc = enqueue_gated_fold(c, r + 1))) return rc;
+            if ((rc = read_commit(c, 2 + r, root))) return rc;
+        }
         if (c->checks && (rc = check_degree(c, 2 + r, (uint32_t)(c->n >> (r + 1)) - ((c->n >> (r + 1)) ? 1 : 0), "prover.rs:228-251 (FRI layer degree)"))) return rc;
         ch.commit_hash(root);                             // prover.rs:224
         memcpy(c->info.roots[2 + r], root, 32);
@@ -747,6 +805,18 @@ static int ctx_make(int device, uint32_t log_n, uint32_t log_b, uint32_t shift, 
     HIPCHK_C(hipHostMalloc((void**)&c->h_mailbox, mail_bytes, hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_mailbox, 0, mail_bytes);
     HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_mailbox, 0));
+    // early launch (zk_ctx_set_early_launch): the gate word and the parameter slots; usable when the device has stream memory operations
+    HIPCHK_C(hipHostMalloc((void**)&c->h_gate, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK_C(hipHostMalloc((void**)&c->h_dyn, 2 * 16 * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_gate, 0, 64);
+    memset(c->h_dyn, 0, 2 * 16 * 4);
+    HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_gate, c->h_gate, 0));
+    HIPCHK_C(hipHostGetDevicePointer((void**)&c->d_dyn, c->h_dyn, 0));
+    {
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+        c->early_ok = can != 0 && !tail;
+    }
     // staging for host-built tree tops and tail layers: one top per tree, the tail layers and their trees, the segment table
     c->stage_words = (size_t)(c->R + 2) * ((size_t)16 << kMaxHostLog) + ((size_t)64 << kMaxHostLog);
     const size_t seg_bytes = 4 * 34 * sizeof(ScatterSeg);
@@ -790,6 +860,8 @@ int zk_ctx_destroy(zk_ctx* c) {
     if (c->h_gather_out) (void)hipHostFree(c->h_gather_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_mailbox) (void)hipHostFree(c->h_mailbox);
+    if (c->h_gate) (void)hipHostFree(c->h_gate);
+    if (c->h_dyn) (void)hipHostFree(c->h_dyn);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     collect_kernel_stats(c);
     delete c->pool;
@@ -813,6 +885,14 @@ int zk_ctx_sync(zk_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
+// Early launch of the FRI rounds' commit launches (include/zkstark_amd.h).  on != 0 where the device has no stream memory
+// operations is accepted and has no effect (results never depend on it).
+int zk_ctx_set_early_launch(zk_ctx* c, int on) {
+    if (!c) return fail(ZK_ERR_INVALID, "null context");
+    c->early = on != 0;
+    return ZK_OK;
+}
+int zk_ctx_get_early_launch(const zk_ctx* c) { return c && c->early && c->early_ok ? 1 : 0; }
 int zk_ctx_set_queries(zk_ctx* c, uint32_t n_queries) {
     if (!c) return fail(ZK_ERR_INVALID, "null context");
     if (n_queries < 1 || n_queries > kMaxQueries) return fail(ZK_ERR_INVALID, "zk_ctx_set_queries: need 1 <= n_queries <= %u", kMaxQueries);

@@ -336,6 +336,11 @@ class Context:
     def set_host_levels(self, top_log, tail_log):
         check(_lib.load().zk_ctx_set_host_levels(self._h, top_log, tail_log))
 
+    def set_early_launch(self, on=True):
+        """zk_ctx_set_early_launch: the next FRI round's launches are enqueued before the current commitment is waited for."""
+        check(_lib.load().zk_ctx_set_early_launch(self._h, int(on)))
+        return bool(_lib.load().zk_ctx_get_early_launch(self._h))
+
     def set_checks(self, on=True):
         """The reference's in-prover assertions (prover.rs:64-66, :148-159/:169, :228-251) inside prove()."""
         check(_lib.load().zk_ctx_set_checks(self._h, int(on)))
