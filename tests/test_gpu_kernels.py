@@ -632,6 +632,24 @@ def test_prove_many_contexts_at_once(zk, orc):
             for p, want in zip(proofs, wants):
                 assert p.data == want.proof and p.state == want.state
         proofs[1].verify(strict=True)
+        # the same with every context's early launch on (the header advises against it when contexts share a GPU -- a stream waiting on
+        # its gate holds a hardware queue -- but it must stay CORRECT and must not deadlock: a gate only ever waits for work that was
+        # enqueued before it), eight contexts on more streams than the device has hardware queues
+        more = [zk.Context(ln, lb) for ln, lb, _ in sizes]
+        try:
+            for c, (ln, lb, a1) in zip(more, sizes):
+                c.trace_upload(zk.trace_fibsq((1 << ln) - 1, 1, a1))
+            on = [c.set_early_launch(True) for c in ctxs + more]
+            for _ in range(5):
+                proofs = zk.prove_many(ctxs + more)
+                for p, want in zip(proofs, wants + wants):
+                    assert p.data == want.proof and p.state == want.state
+            assert all(on) or not any(on)
+            for c in ctxs:
+                c.set_early_launch(False)
+        finally:
+            for c in more:
+                c.close()
         bad = zk.trace_fibsq(4095, 1, 5)
         bad[77] = (int(bad[77]) + 1) % P
         ctxs[3].trace_upload(bad)
