@@ -763,9 +763,14 @@ __device__ __forceinline__ void publish_node(uint32_t* nodes, size_t node, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // wave 0: the eight stores are out before its thread 0 counts
 }
 __device__ __forceinline__ Digest load_digest_agent(const uint32_t* nodes, size_t node) {
+    // four 8-byte agent-scope loads (global_load_dwordx2 ... sc1; a digest is 32-byte aligned)
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(nodes + node * 8);
     Digest d;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d.w[i] = __hip_atomic_load(nodes + node * 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 4; ++i) {
+        const unsigned long long v = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d.w[2 * i] = (uint32_t)v; d.w[2 * i + 1] = (uint32_t)(v >> 32);
+    }
     return d;
 }
 
